@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE package (TEST INFRASTRUCTURE).
+
+Run in the build container only:  python oracle/make_golden.py
+It imports ``nbmf_mm`` from /root/reference/src (never copied into this repo) and stores
+inputs (when not regenerable from a seed) and the reference's outputs as small fixtures.
+The case list is SURVEY.md §8c items 1-9.  The GPU box never runs this script.
+"""
+import os
+import sys
+
+import numpy as np
+
+REF_SRC = "/root/reference/src"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def main():
+    if not os.path.isdir(REF_SRC):
+        sys.exit("reference not present: goldens can only be regenerated in the build container")
+    sys.path.insert(0, REF_SRC)
+    import nbmf_mm  # noqa: F401  (the reference)
+    from nbmf_mm import NBMF, nbmf_mm_solver
+    from nbmf_mm._solver import nbmf_mm_update_beta_dir
+    from nbmf_mm._utils import generate_synthetic_binary_data
+
+    os.makedirs(OUT, exist_ok=True)
+
+    # 1. one-step vectors ------------------------------------------------------------
+    one = {}
+    idx = 0
+    for (m, n, k) in [(20, 30, 4), (64, 48, 5)]:
+        for mkind in ["none", "float", "bool"]:
+            for (al, be) in [(1.2, 1.2), (1.1, 1.3), (0.5, 2.0)]:
+                g = np.random.default_rng(1000 + idx)
+                Y = (g.random((m, n)) < 0.3).astype(np.float64)
+                W = g.uniform(0.1, 0.9, (k, m))
+                W = W / W.sum(axis=0, keepdims=True)
+                H = g.uniform(0.1, 0.9, (k, n))
+                if mkind == "none":
+                    mask = None
+                elif mkind == "float":
+                    mask = (g.random((m, n)) < 0.8).astype(np.float64)
+                else:
+                    mask = g.random((m, n)) < 0.8
+                Wn, Hn = nbmf_mm_update_beta_dir(Y, W, H, mask, al, be, 1e-8)
+                p = f"c{idx}_"
+                one[p + "Y"], one[p + "W"], one[p + "H"] = Y, W, H
+                one[p + "mask"] = np.zeros((0,)) if mask is None else mask
+                one[p + "ab"] = np.array([al, be])
+                one[p + "W_new"], one[p + "H_new"] = Wn, Hn
+                idx += 1
+    # real-valued Y and a weight (non-binary) mask
+    g = np.random.default_rng(77)
+    Y = g.random((24, 40))
+    W = g.uniform(0.1, 0.9, (3, 24)); W /= W.sum(axis=0, keepdims=True)
+    H = g.uniform(0.1, 0.9, (3, 40))
+    mask = g.random((24, 40))
+    Wn, Hn = nbmf_mm_update_beta_dir(Y, W, H, mask, 1.2, 1.2, 1e-8)
+    p = f"c{idx}_"
+    one[p + "Y"], one[p + "W"], one[p + "H"], one[p + "mask"] = Y, W, H, mask
+    one[p + "ab"] = np.array([1.2, 1.2]); one[p + "W_new"], one[p + "H_new"] = Wn, Hn
+    idx += 1
+    one["n_cases"] = np.array(idx)
+    np.savez_compressed(os.path.join(OUT, "one_step.npz"), **one)
+
+    # 2. config-1 curve ----------------------------------------------------------------
+    X = (np.random.default_rng(0).random((100, 500)) < 0.25).astype(np.float64)
+    mdl = NBMF(n_components=6, orientation="beta-dir", alpha=1.2, beta=1.2, random_state=0,
+               max_iter=200, tol=0).fit(X)
+    mdl2 = NBMF(n_components=6, orientation="beta-dir", alpha=1.2, beta=1.2, random_state=0).fit(X)
+    np.savez_compressed(os.path.join(OUT, "config1.npz"), losses=np.array(mdl.loss_curve_), W=mdl.W_,
+                        H=mdl.components_, n_iter=np.array(mdl.n_iter_),
+                        default_n_iter=np.array(mdl2.n_iter_), default_loss=np.array(mdl2.loss_))
+
+    # 3. dir-beta --------------------------------------------------------------------
+    mdl = NBMF(n_components=6, orientation="dir-beta", alpha=1.2, beta=1.2, random_state=0,
+               max_iter=50, tol=0).fit(X)
+    mdlT = NBMF(n_components=6, orientation="beta-dir", alpha=1.2, beta=1.2, random_state=0,
+                max_iter=50, tol=0).fit(X.T)
+    np.savez_compressed(os.path.join(OUT, "dir_beta.npz"), losses=np.array(mdl.loss_curve_), W=mdl.W_,
+                        H=mdl.components_, WT_of_transposed=mdlT.components_.T)
+
+    # 4. masked (float and bool masks) --------------------------------------------------
+    mask = np.random.default_rng(1).random(X.shape) < 0.9
+    mf = NBMF(n_components=6, alpha=1.2, beta=1.2, random_state=0, max_iter=100, tol=0).fit(
+        X, mask=mask.astype(np.float64))
+    mb = NBMF(n_components=6, alpha=1.2, beta=1.2, random_state=0, max_iter=100, tol=0).fit(X, mask=mask)
+    np.savez_compressed(os.path.join(OUT, "masked.npz"), losses_float=np.array(mf.loss_curve_),
+                        losses_bool=np.array(mb.loss_curve_), W=mf.W_, H=mf.components_)
+
+    # 5. real-valued V ---------------------------------------------------------------
+    Xr = np.random.default_rng(3).random((50, 30))
+    mr = NBMF(n_components=5, random_state=1, max_iter=30, tol=0).fit(Xr)
+    np.savez_compressed(os.path.join(OUT, "real_valued.npz"), losses=np.array(mr.loss_curve_), W=mr.W_,
+                        H=mr.components_)
+
+    # 6. custom init (tests/test_strict_parity_optional.py:11-29 recipe) ---------------------
+    r = np.random.default_rng(123)
+    M, N, K = 20, 25, 4
+    Yc = (r.random((M, N)) < 0.3).astype(float)
+    W0 = r.gamma(shape=1.0, scale=1.0, size=(M, K)); W0 /= W0.sum(axis=1, keepdims=True)
+    H0 = np.clip(r.random((K, N)), 1e-6, 1 - 1e-6)
+    mc = NBMF(n_components=K, orientation="beta-dir", alpha=1.2, beta=1.2, random_state=123, max_iter=50,
+              tol=1e-8, W_init=W0, H_init=H0).fit(Yc)
+    md = NBMF(n_components=K, orientation="dir-beta", alpha=1.2, beta=1.2, random_state=123, max_iter=20,
+              tol=0, W_init=np.clip(r.random((M, K)), 1e-3, 1 - 1e-3),
+              H_init=r.uniform(0.1, 0.9, (K, N)))
+    Wd0, Hd0 = md.W_init.copy(), md.H_init.copy()
+    md.fit(Yc)
+    np.savez_compressed(os.path.join(OUT, "custom_init.npz"), Y=Yc, W0=W0, H0=H0, losses=np.array(mc.loss_curve_),
+                        W=mc.W_, H=mc.components_, n_iter=np.array(mc.n_iter_), Wd0=Wd0, Hd0=Hd0,
+                        d_losses=np.array(md.loss_curve_), dW=md.W_, dH=md.components_)
+
+    # 7. stop rule -------------------------------------------------------------------
+    Xs, _, _ = generate_synthetic_binary_data(50, 30, 5, random_state=42)
+    hi = NBMF(n_components=5, tol=0.1, max_iter=1000, random_state=42).fit(Xs)
+    lo = NBMF(n_components=5, tol=1e-8, max_iter=1000, random_state=42).fit(Xs)
+    np.savez_compressed(os.path.join(OUT, "stop_rule.npz"), X=Xs, n_iter_hi=np.array(hi.n_iter_),
+                        n_iter_lo=np.array(lo.n_iter_), loss_hi=np.array(hi.loss_), loss_lo=np.array(lo.loss_),
+                        losses_lo=np.array(lo.loss_curve_))
+
+    # 8. transform / score / perplexity -----------------------------------------------------
+    mt = NBMF(n_components=6, alpha=1.2, beta=1.2, random_state=0, max_iter=60, tol=0).fit(X, mask=mask)
+    Xn = (np.random.default_rng(9).random((10, 500)) < 0.25).astype(np.float64)
+    np.random.seed(5)
+    Wt = mt.transform(Xn)
+    np.random.seed(5)
+    Wtm = mt.transform(X, mask=mask.astype(np.float64))
+    np.random.seed(6)
+    sc = mt.score(X, mask=mask.astype(np.float64))
+    np.random.seed(6)
+    sc_nomask = mt.score(X)
+    np.random.seed(6)
+    pp = mt.perplexity(X, mask=mask.astype(np.float64))
+    np.savez_compressed(os.path.join(OUT, "transform.npz"), H=mt.components_, Wfit=mt.W_, W_new=Wt, W_masked=Wtm,
+                        score=np.array(sc), score_nomask=np.array(sc_nomask), perplexity=np.array(pp))
+
+    # 9. mid-size curves for GPU parity (loss curves only) ----------------------------------
+    g = np.random.default_rng(0)
+    Xm = (g.random((512, 512)) < 0.25).astype(np.float64)
+    Mm = (g.random((512, 512)) < 0.9).astype(np.float64)
+    _, _, l_un, _, _ = nbmf_mm_solver(Xm, 32, max_iter=500, tol=0, random_state=0)
+    _, _, l_mk, _, _ = nbmf_mm_solver(Xm, 32, max_iter=300, tol=0, random_state=0, mask=Mm)
+    _, _, l_db, _, _ = nbmf_mm_solver(Xm[:, :384], 64, max_iter=100, tol=0, random_state=0, orientation="dir-beta",
+                                      mask=Mm[:, :384])
+    g2 = np.random.default_rng(4)
+    Xrv = g2.random((300, 200))
+    Wts = g2.random((300, 200))
+    _, _, l_rv, _, _ = nbmf_mm_solver(Xrv, 16, max_iter=60, tol=0, random_state=2, mask=Wts)
+    np.savez_compressed(os.path.join(OUT, "midsize.npz"), unmasked=np.array(l_un), masked=np.array(l_mk),
+                        dir_beta_masked=np.array(l_db), real_weighted=np.array(l_rv))
+    print("golden fixtures written to", os.path.normpath(OUT))
+    for f in sorted(os.listdir(OUT)):
+        print("  %-20s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return load
+
+
+def config1_X():
+    return (np.random.default_rng(0).random((100, 500)) < 0.25).astype(np.float64)
+
+
+def config1_mask():
+    return np.random.default_rng(1).random((100, 500)) < 0.9
+
+
+def midsize_XM():
+    g = np.random.default_rng(0)
+    X = (g.random((512, 512)) < 0.25).astype(np.float64)
+    M = (g.random((512, 512)) < 0.9).astype(np.float64)
+    return X, M

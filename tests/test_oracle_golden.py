@@ -1,0 +1,152 @@
+"""The CPU oracle (oracle/nbmf_oracle.py) against the reference's own outputs (tests/golden/).
+
+The fixtures were written by oracle/make_golden.py from the imported reference package; this
+file is what "pins" the oracle.  Tolerances: one-step vectors bitwise; long runs <= 1e-13.
+"""
+import numpy as np
+import pytest
+
+from oracle import nbmf_oracle as orc
+from conftest import config1_X, config1_mask, midsize_XM
+
+
+def test_one_step_vectors_bitwise(golden):
+    g = golden("one_step")
+    n = int(g["n_cases"])
+    assert n == 19
+    for i in range(n):
+        p = f"c{i}_"
+        mask = g[p + "mask"]
+        mask = None if mask.size == 0 else mask
+        al, be = g[p + "ab"]
+        Wn, Hn = orc.mm_step(g[p + "Y"], g[p + "W"], g[p + "H"], mask, al, be, 1e-8)
+        np.testing.assert_array_equal(Wn, g[p + "W_new"])
+        np.testing.assert_array_equal(Hn, g[p + "H_new"])
+
+
+def test_config1_curve(golden):
+    g = golden("config1")
+    W, H, losses, t, n_iter = orc.solve(config1_X(), 6, max_iter=200, tol=0, random_state=0)
+    assert t == 0.0 and n_iter == 200 == len(losses)
+    np.testing.assert_array_equal(np.array(losses), g["losses"])
+    assert losses[0] == 0.5839197905454088 and losses[-1] == 0.538276807784136
+    np.testing.assert_array_equal(W, g["W"])
+    np.testing.assert_array_equal(H, g["H"])
+    # default stop rule
+    W, H, losses, _, n_iter = orc.solve(config1_X(), 6, max_iter=2000, tol=1e-5, random_state=0)
+    assert n_iter == int(g["default_n_iter"]) == 286
+    assert losses[-1] == float(g["default_loss"])
+
+
+def test_dir_beta_is_transpose_trick(golden):
+    g = golden("dir_beta")
+    X = config1_X()
+    W, H, losses, _, _ = orc.solve(X, 6, max_iter=50, tol=0, random_state=0, orientation="dir-beta")
+    np.testing.assert_array_equal(np.array(losses), g["losses"])
+    np.testing.assert_array_equal(W, g["W"])
+    np.testing.assert_array_equal(H, g["H"])
+    np.testing.assert_array_equal(W, g["WT_of_transposed"])
+    assert losses[0] == 0.569955714879511 and losses[-1] == 0.530914444658953
+
+
+def test_masked_float_and_bool(golden):
+    g = golden("masked")
+    X, mask = config1_X(), config1_mask()
+    for mk, key in [(mask.astype(np.float64), "losses_float"), (mask, "losses_bool")]:
+        W, H, losses, _, _ = orc.solve(X, 6, max_iter=100, tol=0, random_state=0, mask=mk)
+        np.testing.assert_array_equal(np.array(losses), g[key])
+    assert losses[-1] == 0.571261867312102
+    assert all(losses[i] <= losses[i - 1] + 1e-12 for i in range(1, len(losses)))
+
+
+def test_real_valued(golden):
+    g = golden("real_valued")
+    Xr = np.random.default_rng(3).random((50, 30))
+    W, H, losses, _, _ = orc.solve(Xr, 5, max_iter=30, tol=0, random_state=1)
+    np.testing.assert_array_equal(np.array(losses), g["losses"])
+    assert losses[-1] == 0.6885711077057329
+    np.testing.assert_array_equal(W, g["W"])
+
+
+def test_custom_init_both_orientations(golden):
+    g = golden("custom_init")
+    W, H, losses, _, n_iter = orc.solve(g["Y"], 4, max_iter=50, tol=1e-8, random_state=123,
+                                        W_init=g["W0"], H_init=g["H0"])
+    assert n_iter == int(g["n_iter"])
+    np.testing.assert_array_equal(np.array(losses), g["losses"])
+    np.testing.assert_array_equal(W, g["W"])
+    W, H, losses, _, _ = orc.solve(g["Y"], 4, max_iter=20, tol=0, random_state=123, orientation="dir-beta",
+                                   W_init=g["Wd0"], H_init=g["Hd0"])
+    np.testing.assert_array_equal(np.array(losses), g["d_losses"])
+    np.testing.assert_array_equal(W, g["dW"])
+    np.testing.assert_array_equal(H, g["dH"])
+
+
+def test_dir_beta_single_init_shape_error(golden):
+    g = golden("custom_init")
+    with pytest.raises(ValueError):  # only one init given under dir-beta, non-square V
+        orc.solve(g["Y"], 4, max_iter=2, random_state=0, orientation="dir-beta", W_init=g["Wd0"])
+
+
+def test_stop_rule_counts(golden):
+    g = golden("stop_rule")
+    _, _, l_hi, _, n_hi = orc.solve(g["X"], 5, max_iter=1000, tol=0.1, random_state=42)
+    _, _, l_lo, _, n_lo = orc.solve(g["X"], 5, max_iter=1000, tol=1e-8, random_state=42)
+    assert n_hi == int(g["n_iter_hi"]) and n_lo == int(g["n_iter_lo"])
+    assert n_hi < 50 < n_lo
+    assert l_hi[-1] == float(g["loss_hi"]) and l_lo[-1] == float(g["loss_lo"])
+
+
+def test_transform_and_score(golden):
+    g = golden("transform")
+    X, mask = config1_X(), config1_mask().astype(np.float64)
+    Xn = (np.random.default_rng(9).random((10, 500)) < 0.25).astype(np.float64)
+    np.random.seed(5)
+    np.testing.assert_array_equal(orc.w_only_transform(Xn, g["H"]), g["W_new"])
+    np.random.seed(5)
+    np.testing.assert_array_equal(orc.w_only_transform(X, g["H"], mask=mask), g["W_masked"])
+    np.random.seed(6)
+    Wt = orc.w_only_transform(X, g["H"])          # score() transforms WITHOUT the mask (_base.py:235)
+    assert orc.score(X, Wt, g["H"], mask) == float(g["score"])
+    assert orc.score(X, Wt, g["H"]) == float(g["score_nomask"])
+    assert np.exp(-orc.score(X, Wt, g["H"], mask)) == float(g["perplexity"])
+
+
+def test_midsize_curves(golden):
+    g = golden("midsize")
+    X, M = midsize_XM()
+    _, _, l, _, _ = orc.solve(X, 32, max_iter=40, tol=0, random_state=0)
+    np.testing.assert_allclose(np.array(l), g["unmasked"][:40], rtol=1e-13, atol=0)
+    _, _, l, _, _ = orc.solve(X, 32, max_iter=40, tol=0, random_state=0, mask=M)
+    np.testing.assert_allclose(np.array(l), g["masked"][:40], rtol=1e-13, atol=0)
+    assert g["unmasked"][499] == 0.5264565431072413 and g["masked"][299] == 0.5564032258894519
+    _, _, l, _, _ = orc.solve(X[:, :384], 64, max_iter=30, tol=0, random_state=0, orientation="dir-beta",
+                              mask=M[:, :384])
+    np.testing.assert_allclose(np.array(l), g["dir_beta_masked"][:30], rtol=1e-13, atol=0)
+
+
+def test_duchi_projection_properties():
+    """Extension (parity unpinned): Euclidean projection onto the simplex, checked by properties
+    and against a brute-force search on tiny K."""
+    r = np.random.default_rng(0)
+    v = r.normal(size=(7, 200)) * 2
+    p = orc.project_simplex_sort(v)
+    np.testing.assert_allclose(p.sum(axis=0), 1.0, atol=1e-12)
+    assert (p >= 0).all()
+    np.testing.assert_allclose(orc.project_simplex_sort(p), p, atol=1e-12)   # idempotent
+    # optimality: no feasible random point is closer
+    for c in range(20):
+        q = r.dirichlet(np.ones(7), size=2000).T
+        d_best = np.sum((p[:, [c]] - v[:, [c]]) ** 2)
+        assert (np.sum((q - v[:, [c]]) ** 2, axis=0) >= d_best - 1e-12).all()
+    # points already on the simplex are fixed points
+    s = r.dirichlet(np.ones(5), size=50).T
+    np.testing.assert_allclose(orc.project_simplex_sort(s), s, atol=1e-15)
+
+
+def test_duchi_step_close_to_normalize_when_unmasked():
+    X = config1_X()
+    _, _, l_n, _, _ = orc.solve(X, 6, max_iter=30, tol=0, random_state=0)
+    W, H, l_d, _, _ = orc.solve(X, 6, max_iter=30, tol=0, random_state=0, step=orc.mm_step_duchi)
+    np.testing.assert_allclose(l_d, l_n, rtol=1e-6)  # eps makes sum(W*Q)/n = 1 - O(1e-8): shift vs rescale
+    np.testing.assert_allclose(W.sum(axis=1), 1.0, atol=1e-12)
