@@ -1,0 +1,115 @@
+/*
+ * nbmf_hip.h — C ABI of libnbmf_hip.so: the MI355X (gfx950) implementation of the NBMF-MM
+ * multiplicative-update inner loop.
+ *
+ * The reference (siddC/nbmf_mm) has no FFI of its own: its seam is the Python call
+ *   nbmf_mm_solver(...)            src/nbmf_mm/_solver.py:61-216   (outer loop)
+ *   nbmf_mm_update_beta_dir(...)   src/nbmf_mm/_solver.py:5-59     (one MM iteration)
+ *   NBMFMM.transform(...)          src/nbmf_mm/_base.py:162-199    (simplex-factor-only loop)
+ * Each entry point below names the reference lines it replaces.  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add to call this library from _solver.py.
+ *
+ * Conventions
+ *   - every function returns 0 (NBMF_OK) or a negative NBMF_ERR_* code; nbmf_last_error() gives the
+ *     message of the last failure on the calling thread;
+ *   - host buffers are caller-owned, C-contiguous (row-major), float64 unless stated, and are copied
+ *     during the call; device memory is owned by the context;
+ *   - INTERNAL LAYOUT (that of _solver.py after its orientation transpose, :113-136): the data matrix
+ *     Y is m x n, the simplex factor W is k x m (columns sum to 1), the Beta factor H is k x n;
+ *   - a context is not thread-safe; distinct contexts are independent; one context = one GPU.
+ *     Row-sharded multi-GPU runs use one process (and one context) per GPU, joined by
+ *     nbmf_comm_init (RCCL all-reduce of the k x n H-step products each iteration).
+ */
+#ifndef NBMF_HIP_H
+#define NBMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBMF_OK 0
+#define NBMF_ERR_ARG (-1)       /* bad argument (shape, NULL, unsupported k) */
+#define NBMF_ERR_HIP (-2)       /* a HIP runtime call failed, or no gfx950 device */
+#define NBMF_ERR_RANGE (-3)     /* data outside [0,1]: the caller raises ValueError("X must be binary"), _base.py:90-91 */
+#define NBMF_ERR_STATE (-4)     /* call order violated (e.g. run before upload) */
+#define NBMF_ERR_COMM (-5)      /* RCCL failure */
+
+#define NBMF_MASK_NONE 0
+#define NBMF_MASK_F64 1         /* float64 weights; Y*mask semantics of _solver.py:30-32 */
+#define NBMF_MASK_U8 2          /* bool / uint8, nonzero = observed */
+
+#define NBMF_PROJ_NORMALIZE 0   /* the reference path: /n then column renormalise, _solver.py:54,57 */
+#define NBMF_PROJ_DUCHI 1       /* README.md:27-35 extension: per-row observed count, Euclidean projection */
+
+#define NBMF_FLAG_BINARY_PATH 1 /* out_flags bit: data was {0,1} (and mask {0,1}) -> 1 byte/entry storage */
+
+#define NBMF_MAX_K 128
+
+typedef struct nbmf_ctx nbmf_ctx;
+
+/* library / device ------------------------------------------------------------------------ */
+int nbmf_abi_version(void);
+const char* nbmf_last_error(void);
+int nbmf_device_count(int* count);
+
+/* Create a context for an m x n internal problem with k components on HIP device `device`.
+ * Replaces the implicit NumPy allocations of _solver.py:109-136. */
+int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out);
+int nbmf_destroy(nbmf_ctx* ctx);
+
+/* Hyper-parameters of nbmf_mm_solver (_solver.py:66-67,74) plus the projection extension. */
+int nbmf_set_hyper(nbmf_ctx* ctx, double alpha, double beta, double eps, int projection);
+
+/* Upload the data matrix and optional mask (replaces the per-iteration Y*mask, Y.T*mask.T,
+ * (1-Y).T*mask.T products of _solver.py:22-32 by a one-time pack into MFMA tile order).
+ *   transposed = 0: x is the m x n internal matrix, leading dimension ldx (elements);
+ *   transposed = 1: x is n x m (the user's V under orientation="dir-beta", _solver.py:113-120)
+ *                   and Y = x^T; the mask has the same shape/orientation as x.
+ * mask may be NULL (mask_kind NBMF_MASK_NONE).  out_flags (may be NULL) receives NBMF_FLAG_*.
+ * Returns NBMF_ERR_RANGE if any entry of x is outside [0,1] or not finite. */
+int nbmf_upload(nbmf_ctx* ctx, const double* x, int64_t ldx, int transposed,
+                const void* mask, int mask_kind, int64_t ldmask, int* out_flags);
+
+/* Number of observed entries held by this context: Y.size or count_nonzero(mask), _solver.py:151,155. */
+int nbmf_get_n_obs(nbmf_ctx* ctx, double* n_obs);
+
+/* Factors in internal layout: W is k x m, H is k x n, C-contiguous (_solver.py:132-136; the caller
+ * has already drawn / transposed / column-normalised them). */
+int nbmf_set_factors(nbmf_ctx* ctx, const double* W_kxm, const double* H_kxn);
+int nbmf_get_factors(nbmf_ctx* ctx, double* W_kxm, double* H_kxn);
+
+/* The hot loop, _solver.py:143-175: up to max_iter MM iterations (H-step, W-step, loss) with the
+ * relative-change stop rule (:169-174, checked on device).  losses must hold max_iter doubles;
+ * *n_iter receives iteration+1 (:215).  Factors stay on the device (nbmf_get_factors). */
+int nbmf_run(nbmf_ctx* ctx, int max_iter, double tol, double* losses, int* n_iter);
+
+/* n_steps repetitions of the simplex-factor update with the Beta factor frozen: the loop body of
+ * NBMFMM.transform, _base.py:178-193 (always "normalize", eps as set by nbmf_set_hyper). */
+int nbmf_w_only_steps(nbmf_ctx* ctx, int n_steps);
+
+/* Loss of the current factors, _solver.py:148-162. */
+int nbmf_loss(nbmf_ctx* ctx, double* loss);
+
+/* Multi-GPU (row-sharded Y): rank 0 calls nbmf_comm_unique_id and distributes the 128 bytes; every
+ * rank then calls nbmf_comm_init.  After it, nbmf_run all-reduces the k x n H-step products
+ * [P1|P2|loglik] over RCCL each iteration and uses the global observed count.  No reference
+ * counterpart (the reference is single-process). */
+int nbmf_comm_unique_id(void* id128);
+int nbmf_comm_init(nbmf_ctx* ctx, const void* id128, int nranks, int rank);
+
+/* Measurement: HIP-event timing of the two fused pass kernels on the context's stream. */
+int nbmf_timing_enable(nbmf_ctx* ctx, int enable);
+/* ms summed over launches since enable, and launch counts; any pointer may be NULL. */
+int nbmf_timing_get(nbmf_ctx* ctx, double* hpass_ms, int* hpass_launches, double* wpass_ms, int* wpass_launches);
+int nbmf_synchronize(nbmf_ctx* ctx);
+
+/* Self-test hook used by the GPU tests: max relative error of the kernel's Newton reciprocal
+ * against IEEE division over n samples of the denominator range [eps, 1+eps]. */
+int nbmf_selftest_rcp(int device, int n, double* max_rel_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBMF_HIP_H */

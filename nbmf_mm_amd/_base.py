@@ -1,0 +1,153 @@
+"""scikit-learn style estimator with the reference's public surface
+(src/nbmf_mm/_base.py:7-269): same constructor arguments, methods, attributes, orientation
+aliases and error messages; ``fit`` and ``transform`` run on an MI355X through libnbmf_hip.
+"""
+import numpy as np
+from sklearn.base import BaseEstimator, TransformerMixin
+from sklearn.utils import check_array
+
+from ._solver import nbmf_mm_solver, w_only_transform
+from ._utils import check_is_fitted
+
+# exact-string alias table of src/nbmf_mm/_base.py:127-137 (not case-folding)
+_ORIENTATION_ALIASES = {
+    "beta-dir": "beta-dir",
+    "dir-beta": "dir-beta",
+    "Beta-Dir": "beta-dir",
+    "Dir-Beta": "dir-beta",
+    "Dir Beta": "dir-beta",
+    "binary ICA": "beta-dir",
+    "Binary ICA": "beta-dir",
+    "bICA": "beta-dir",
+    "Aspect Bernoulli": "dir-beta",
+}
+
+
+class NBMFMM(BaseEstimator, TransformerMixin):
+    """Mean-parameterised Bernoulli matrix factorisation by majorisation-minimisation
+    (Magron & Fevotte 2022), GPU-resident.
+
+    Parameters follow src/nbmf_mm/_base.py:63-66.  Extensions: ``projection`` (alias
+    ``projection_method``) in {"normalize", "duchi"} (README.md:27-35 of the reference), ``n_init``
+    (README.md:144: keep the best of several random restarts) and ``device``.
+
+    Attributes after ``fit``: ``W_`` (n_samples, k), ``components_`` (k, n_features),
+    ``loss_curve_`` / ``objective_history_``, ``loss_`` / ``reconstruction_err_``, ``n_iter_``
+    (_base.py:114-120).
+    """
+
+    def __init__(self, n_components=10, alpha=1.2, beta=1.2, max_iter=2000, tol=1e-5, W_init=None,
+                 H_init=None, init=None, random_state=None, verbose=0, orientation="beta-dir",
+                 projection="normalize", projection_method=None, n_init=1, device=0):
+        self.n_components = n_components
+        self.alpha = alpha
+        self.beta = beta
+        self.max_iter = max_iter
+        self.tol = tol
+        self.W_init = W_init
+        self.H_init = H_init
+        self.init = init            # accepted and ignored, as in the reference (_base.py:74)
+        self.random_state = random_state
+        self.verbose = verbose
+        self.orientation = orientation
+        self.projection = projection
+        self.projection_method = projection_method
+        self.n_init = n_init
+        self.device = device
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _normalize_orientation(self, orientation):
+        try:
+            return _ORIENTATION_ALIASES[orientation]
+        except (KeyError, TypeError):
+            raise ValueError(f"Unknown orientation: {orientation}. "
+                             f"Must be one of {list(_ORIENTATION_ALIASES.keys())}") from None
+
+    def _projection(self):
+        return self.projection_method if self.projection_method is not None else self.projection
+
+    @staticmethod
+    def _validated(X):
+        X = check_array(X, accept_sparse="csr", dtype=np.float64)     # _base.py:83
+        if hasattr(X, "toarray"):
+            X = X.toarray()                                            # :86-87
+        return X
+
+    # -- estimator API ---------------------------------------------------------------------------
+    def fit(self, X, y=None, mask=None):
+        """Fit the factorisation to X (entries in [0, 1]); ``mask`` marks observed entries."""
+        X = self._validated(X)
+        if not np.all((X >= 0) & (X <= 1)):
+            raise ValueError("X must be binary")                      # :90-91
+        orientation = self._normalize_orientation(self.orientation)
+        self.orientation = orientation                                # written back, :95
+        n_init = int(self.n_init)
+        if n_init < 1:
+            raise ValueError("n_init must be >= 1")
+        best = None
+        for r in range(n_init):
+            seed = self.random_state
+            if r > 0 and seed is not None:
+                seed = seed + r                                       # restarts: consecutive seeds
+            result = nbmf_mm_solver(
+                Y=X, n_components=self.n_components, max_iter=self.max_iter, tol=self.tol,
+                alpha=self.alpha, beta=self.beta, W_init=self.W_init, H_init=self.H_init, mask=mask,
+                random_state=seed, verbose=self.verbose, orientation=orientation,
+                projection=self._projection(), device=self.device)
+            if best is None or result[2][-1] < best[2][-1]:
+                best = result
+        W, H, losses, _, n_iter = best
+        self.W_ = W
+        self.components_ = H
+        self.loss_curve_ = losses
+        self.objective_history_ = losses
+        self.loss_ = losses[-1] if losses else np.inf
+        self.n_iter_ = n_iter
+        self.reconstruction_err_ = losses[-1] if losses else np.inf
+        return self
+
+    def fit_transform(self, X, y=None):
+        """Fit and return ``W_`` (no mask argument, as _base.py:145-160)."""
+        self.fit(X)
+        return self.W_
+
+    def transform(self, X, mask=None):
+        """Find W for new rows X with ``components_`` frozen: 50 simplex-factor updates from a
+        draw of the global NumPy RNG (_base.py:162-199)."""
+        check_is_fitted(self, ["components_"])
+        X = self._validated(X)
+        if mask is not None and hasattr(mask, "toarray"):
+            mask = mask.toarray()
+        return w_only_transform(X, self.components_, mask=mask, n_iter=50, device=self.device)
+
+    def inverse_transform(self, W):
+        """clip(W @ components_, 0, 1) (_base.py:201-210)."""
+        check_is_fitted(self, ["components_"])
+        W = check_array(W, dtype=np.float64)
+        return np.clip(W @ self.components_, 0.0, 1.0)
+
+    def score(self, X, mask=None):
+        """Mean log-likelihood per observed entry of the reconstruction (_base.py:212-247).
+        As in the reference the inner ``transform`` is called WITHOUT the mask (:235)."""
+        check_is_fitted(self, ["components_"])
+        X = self._validated(X)
+        recon = self.inverse_transform(self.transform(X))
+        eps = 1e-8
+        if mask is None:
+            ll = X * np.log(recon + eps) + (1 - X) * np.log(1 - recon + eps)
+            n_obs = X.size
+        else:
+            if hasattr(mask, "toarray"):
+                mask = mask.toarray()
+            xm = X * mask
+            ll = xm * np.log(recon + eps) + (1 - xm) * np.log(1 - recon + eps)
+            n_obs = np.count_nonzero(mask)
+        return np.sum(ll) / n_obs
+
+    def perplexity(self, X, mask=None):
+        """exp(-score) (_base.py:249-265)."""
+        return np.exp(-self.score(X, mask))
+
+
+# alias kept for backwards compatibility (_base.py:269)
+NBMF = NBMFMM

@@ -1,0 +1,218 @@
+"""ctypes binding of libnbmf_hip.so (see include/nbmf_hip.h for the C ABI).
+
+The library is the product path: if it is missing, or there is no MI355X, every entry point
+raises — there is no CPU fallback (the CPU oracle under oracle/ is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+NBMF_OK = 0
+NBMF_ERR_ARG = -1
+NBMF_ERR_HIP = -2
+NBMF_ERR_RANGE = -3
+NBMF_ERR_STATE = -4
+NBMF_ERR_COMM = -5
+
+MASK_NONE, MASK_F64, MASK_U8 = 0, 1, 2
+PROJ_NORMALIZE, PROJ_DUCHI = 0, 1
+FLAG_BINARY_PATH = 1
+MAX_K = 128
+
+#: every symbol include/nbmf_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "nbmf_abi_version", "nbmf_last_error", "nbmf_device_count", "nbmf_create", "nbmf_destroy",
+    "nbmf_set_hyper", "nbmf_upload", "nbmf_get_n_obs", "nbmf_set_factors", "nbmf_get_factors",
+    "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_comm_unique_id", "nbmf_comm_init",
+    "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_rcp",
+]
+
+
+class NBMFHipError(RuntimeError):
+    """A libnbmf_hip call failed (HIP error, missing GPU, bad state)."""
+
+
+def library_path() -> str:
+    return os.environ.get("NBMF_HIP_LIBRARY", os.path.join(_HERE, "libnbmf_hip.so"))
+
+
+_lib = None
+
+
+def load():
+    """Load libnbmf_hip.so (built by nbmf_mm_amd/csrc/Makefile or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise NBMFHipError(
+            f"{path} not found: build it with `make -C nbmf_mm_amd/csrc` (needs hipcc); "
+            "nbmf_mm_amd has no CPU fallback")
+    lib = ctypes.CDLL(path)
+    dp = POINTER(c_double)
+    lib.nbmf_abi_version.restype = c_int
+    lib.nbmf_last_error.restype = c_char_p
+    lib.nbmf_device_count.argtypes = [POINTER(c_int)]
+    lib.nbmf_create.argtypes = [c_int64, c_int64, c_int, c_int, POINTER(c_void_p)]
+    lib.nbmf_destroy.argtypes = [c_void_p]
+    lib.nbmf_set_hyper.argtypes = [c_void_p, c_double, c_double, c_double, c_int]
+    lib.nbmf_upload.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, POINTER(c_int)]
+    lib.nbmf_get_n_obs.argtypes = [c_void_p, dp]
+    lib.nbmf_set_factors.argtypes = [c_void_p, c_void_p, c_void_p]
+    lib.nbmf_get_factors.argtypes = [c_void_p, c_void_p, c_void_p]
+    lib.nbmf_run.argtypes = [c_void_p, c_int, c_double, c_void_p, POINTER(c_int)]
+    lib.nbmf_w_only_steps.argtypes = [c_void_p, c_int]
+    lib.nbmf_loss.argtypes = [c_void_p, dp]
+    lib.nbmf_comm_unique_id.argtypes = [c_void_p]
+    lib.nbmf_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
+    lib.nbmf_timing_enable.argtypes = [c_void_p, c_int]
+    lib.nbmf_timing_get.argtypes = [c_void_p, dp, POINTER(c_int), dp, POINTER(c_int)]
+    lib.nbmf_synchronize.argtypes = [c_void_p]
+    lib.nbmf_selftest_rcp.argtypes = [c_int, c_int, dp]
+    for name in SYMBOLS:
+        if name != "nbmf_last_error":
+            getattr(lib, name).restype = c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc == NBMF_OK:
+        return
+    msg = load().nbmf_last_error().decode("utf-8", "replace")
+    if rc == NBMF_ERR_RANGE:
+        raise ValueError("X must be binary")          # _base.py:91 wording
+    if rc == NBMF_ERR_ARG:
+        raise ValueError(msg)
+    raise NBMFHipError(msg)
+
+
+def device_count() -> int:
+    n = c_int(0)
+    rc = load().nbmf_device_count(byref(n))
+    return n.value if rc == NBMF_OK else 0
+
+
+def _f64c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    """One m x n x k internal problem on one GPU (internal layout: Y m x n, W k x m, H k x n)."""
+
+    def __init__(self, m, n, k, device=0):
+        self._lib = load()
+        self._h = c_void_p()
+        _check(self._lib.nbmf_create(int(m), int(n), int(k), int(device), byref(self._h)))
+        self.m, self.n, self.k = int(m), int(n), int(k)
+        self.binary_path = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.nbmf_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_hyper(self, alpha, beta, eps=1e-8, projection=PROJ_NORMALIZE):
+        _check(self._lib.nbmf_set_hyper(self._h, float(alpha), float(beta), float(eps), int(projection)))
+
+    def upload(self, x, mask=None, transposed=False):
+        """x: the m x n internal matrix, or (transposed=True) the n x m user matrix whose transpose it is."""
+        x = _f64c(x)
+        want = (self.n, self.m) if transposed else (self.m, self.n)
+        if x.shape != want:
+            raise ValueError(f"data has shape {x.shape}, context expects {want}")
+        kind, mptr, ldm = MASK_NONE, None, 0
+        if mask is not None:
+            mask = np.asarray(mask)
+            if mask.shape != x.shape:
+                mask = np.broadcast_to(mask, x.shape)      # Y * mask broadcasting, _solver.py:30
+            if mask.dtype == np.bool_ or mask.dtype == np.uint8:
+                mask = np.ascontiguousarray(mask).view(np.uint8)
+                kind = MASK_U8
+            else:
+                mask = _f64c(mask)
+                kind = MASK_F64
+            mptr, ldm = mask.ctypes.data_as(c_void_p), mask.shape[1]
+        flags = c_int(0)
+        _check(self._lib.nbmf_upload(self._h, x.ctypes.data_as(c_void_p), x.shape[1], int(bool(transposed)),
+                                     mptr, kind, ldm, byref(flags)))
+        self.binary_path = bool(flags.value & FLAG_BINARY_PATH)
+        return self.binary_path
+
+    def n_obs(self):
+        v = c_double(0)
+        _check(self._lib.nbmf_get_n_obs(self._h, byref(v)))
+        return v.value
+
+    def set_factors(self, W_kxm, H_kxn):
+        W, H = _f64c(W_kxm), _f64c(H_kxn)
+        if W.shape != (self.k, self.m) or H.shape != (self.k, self.n):
+            raise ValueError(f"factor shapes {W.shape}, {H.shape} do not match (k,m)=({self.k},{self.m}), "
+                             f"(k,n)=({self.k},{self.n})")
+        _check(self._lib.nbmf_set_factors(self._h, W.ctypes.data_as(c_void_p), H.ctypes.data_as(c_void_p)))
+
+    def get_factors(self):
+        W = np.empty((self.k, self.m), dtype=np.float64)
+        H = np.empty((self.k, self.n), dtype=np.float64)
+        _check(self._lib.nbmf_get_factors(self._h, W.ctypes.data_as(c_void_p), H.ctypes.data_as(c_void_p)))
+        return W, H
+
+    def run(self, max_iter, tol):
+        losses = np.empty(int(max_iter), dtype=np.float64)
+        n_iter = c_int(0)
+        _check(self._lib.nbmf_run(self._h, int(max_iter), float(tol), losses.ctypes.data_as(c_void_p), byref(n_iter)))
+        return losses[: n_iter.value].copy(), n_iter.value
+
+    def w_only_steps(self, n_steps):
+        _check(self._lib.nbmf_w_only_steps(self._h, int(n_steps)))
+
+    def loss(self):
+        v = c_double(0)
+        _check(self._lib.nbmf_loss(self._h, byref(v)))
+        return v.value
+
+    def comm_init(self, uid: bytes, nranks: int, rank: int):
+        buf = ctypes.create_string_buffer(bytes(uid), 128)
+        _check(self._lib.nbmf_comm_init(self._h, buf, int(nranks), int(rank)))
+
+    def timing_enable(self, on=True):
+        _check(self._lib.nbmf_timing_enable(self._h, int(bool(on))))
+
+    def timing(self):
+        hm, wm, hn, wn = c_double(0), c_double(0), c_int(0), c_int(0)
+        _check(self._lib.nbmf_timing_get(self._h, byref(hm), byref(hn), byref(wm), byref(wn)))
+        return {"hpass_ms": hm.value, "hpass_launches": hn.value, "wpass_ms": wm.value, "wpass_launches": wn.value}
+
+    def synchronize(self):
+        _check(self._lib.nbmf_synchronize(self._h))
+
+
+def comm_unique_id() -> bytes:
+    buf = ctypes.create_string_buffer(128)
+    _check(load().nbmf_comm_unique_id(buf))
+    return buf.raw
+
+
+def selftest_rcp(n=1 << 20, device=0) -> float:
+    v = c_double(0)
+    _check(load().nbmf_selftest_rcp(int(device), int(n), byref(v)))
+    return v.value

@@ -1,0 +1,127 @@
+"""Host side of the solver: same signature and return value as the reference's
+``nbmf_mm_solver`` (src/nbmf_mm/_solver.py:61-216), with the hot loop (:143-175) executed by
+libnbmf_hip on an MI355X.  Seeding, init draws, the orientation transpose and the final
+simplex touch-up stay on the host exactly as the reference orders them.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _hip
+
+_PROJECTIONS = {"normalize": _hip.PROJ_NORMALIZE, "duchi": _hip.PROJ_DUCHI}
+
+
+def _projection_code(projection):
+    if projection not in _PROJECTIONS:
+        raise ValueError(f"Unknown projection: {projection}. Must be one of {list(_PROJECTIONS)}")
+    return _PROJECTIONS[projection]
+
+
+def _draw_init(m, k, n, W_init, H_init):
+    """Init draws in the reference's order: W (m,k) first, then H (k,n); each only if absent
+    (src/nbmf_mm/_solver.py:126-129)."""
+    if W_init is None:
+        W_init = np.random.uniform(0.1, 0.9, (m, k))
+    if H_init is None:
+        H_init = np.random.uniform(0.1, 0.9, (k, n))
+    return W_init, H_init
+
+
+def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None,
+                   H_init=None, mask=None, random_state=None, verbose=0, orientation="beta-dir",
+                   eps=1e-8, projection="normalize", device=0, _ctx_hook=None):
+    """NBMF-MM on the GPU.  Returns ``(W (m,k), H (k,n), losses, 0.0, n_iter)``.
+
+    Mirrors src/nbmf_mm/_solver.py:61-216 argument for argument; ``projection`` and ``device``
+    are extensions.  ``time_elapsed`` is 0.0 as in the reference (:216).
+    """
+    proj = _projection_code(projection)
+    if int(max_iter) < 1:
+        raise ValueError("max_iter must be >= 1")      # the reference dies with UnboundLocalError here (:215)
+    if random_state is not None:
+        np.random.seed(random_state)                   # GLOBAL legacy RNG, as :102-103
+    if mask is not None and hasattr(mask, "toarray"):
+        mask = mask.toarray()                          # :106-107
+    Y = np.asarray(Y)
+    m, n = Y.shape
+    k = int(n_components)
+    transposed = orientation == "dir-beta"
+    if transposed:                                     # transpose trick, :113-123
+        m, n = n, m
+        if W_init is not None and H_init is not None:
+            W_init, H_init = np.asarray(H_init).T, np.asarray(W_init).T
+    W_init, H_init = _draw_init(m, k, n, W_init, H_init)
+    W = np.asarray(W_init, dtype=np.float64).T         # (k, m), :132
+    H = np.asarray(H_init, dtype=np.float64)           # (k, n), :133
+    W = W / W.sum(axis=0, keepdims=True)               # :136 (a wrong-shaped init raises here, as in the reference)
+    if W.shape != (k, m) or H.shape != (k, n):
+        raise ValueError(f"operands could not be broadcast together: W_init/H_init give {W.shape}, {H.shape}; "
+                         f"expected ({k},{m}), ({k},{n})")
+
+    with _hip.Context(m, n, k, device=device) as ctx:
+        ctx.set_hyper(alpha, beta, eps, proj)
+        # the user's array goes up untransposed; the pack kernel applies the orientation
+        ctx.upload(Y, mask=mask, transposed=transposed)
+        if _ctx_hook is not None:
+            _ctx_hook(ctx)
+        ctx.set_factors(W, H)
+        losses, n_iter = ctx.run(int(max_iter), float(tol))
+        Wk, Hk = ctx.get_factors()
+
+    losses = [float(v) for v in losses]
+    if verbose > 0:                                    # same text as :165-166,172-173 (printed after the run)
+        for it, loss in enumerate(losses):
+            if it % 10 == 0:
+                print(f"Iter {it:4d}: Loss = {loss:.6f}")
+        if n_iter < int(max_iter) or (n_iter > 1 and losses[-2] != 0 and
+                                      abs(losses[-2] - losses[-1]) / abs(losses[-2]) < tol):
+            print(f"Converged at iteration {n_iter - 1}")
+
+    W_final, H_final = Wk.T, Hk                        # :178-179
+    if transposed:
+        W_final, H_final = H_final.T, W_final.T        # :182-184
+    W_final, H_final = _touch_up(W_final, H_final, orientation)
+    return W_final, H_final, losses, 0.0, n_iter
+
+
+def _touch_up(W_final, H_final, orientation):
+    """Final renormalisation only where the simplex sums drifted by more than 1e-9
+    (src/nbmf_mm/_solver.py:192-213); normally a no-op."""
+    if orientation == "beta-dir":
+        sums = W_final.sum(axis=1, keepdims=True)
+        dev = np.max(np.abs(sums - 1.0)) if sums.size else 0.0
+        if np.isfinite(dev) and dev > 1e-9:
+            ok = (sums > 1e-12).ravel()
+            if np.any(ok):
+                W_final = np.array(W_final)
+                W_final[ok, :] = W_final[ok, :] / sums[ok]
+    else:
+        sums = H_final.sum(axis=0, keepdims=True)
+        dev = np.max(np.abs(sums - 1.0)) if sums.size else 0.0
+        if np.isfinite(dev) and dev > 1e-9:
+            ok = (sums > 1e-12).ravel()
+            if np.any(ok):
+                H_final = np.array(H_final)
+                H_final[:, ok] = H_final[:, ok] / sums[:, ok]
+    return W_final, H_final
+
+
+def w_only_transform(X, H, mask=None, W0=None, n_iter=50, device=0):
+    """The loop of ``NBMFMM.transform`` (src/nbmf_mm/_base.py:170-199) on the GPU: ``n_iter``
+    simplex-factor updates with ``H`` frozen, then clip to [1e-8, 1] and row-renormalise."""
+    X = np.asarray(X, dtype=np.float64)
+    m, n = X.shape
+    k = H.shape[0]
+    if W0 is None:
+        W0 = np.random.uniform(0.1, 0.9, (m, k))      # global RNG, :175
+    with _hip.Context(m, n, k, device=device) as ctx:
+        ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_NORMALIZE)   # eps is hard-coded 1e-8 at :190
+        ctx.upload(X, mask=mask, transposed=False)
+        ctx.set_factors(np.ascontiguousarray(W0.T), H)
+        ctx.w_only_steps(int(n_iter))
+        Wk, _ = ctx.get_factors()
+    W = Wk.T
+    W = np.clip(W, 1e-8, 1.0)                          # :196
+    W = W / W.sum(axis=1, keepdims=True)               # :198
+    return W

@@ -1,0 +1,1332 @@
+// libnbmf_hip — NBMF-MM multiplicative-update inner loop for MI355X (gfx950 / CDNA4).
+//
+// What runs here (reference: siddC/nbmf_mm, src/nbmf_mm/_solver.py:5-59 and :143-175):
+//   H-pass   one fused sweep over Y:  Theta = W^T H (f64 MFMA) -> ratios -> P1 = W R1, P2 = W R2
+//            (f64 MFMA, Theta's accumulator registers are the B operands) + log-likelihood of the
+//            CURRENT factors (= the loss of the previous iteration, _solver.py:148-155).
+//   H-update k x n Beta-MAP update (_solver.py:42-47) + Beta log-prior sums (:158-159).
+//   W-pass   one fused sweep over Y^T: Theta' = H'^T W -> ratios -> Q = H'(S1-S2)^T + 1 (x) sum S2
+//            (algebraically _solver.py:53; one back-product instead of two).
+//   W-update k x m multiplicative step, /n, column renormalise (_solver.py:53-57) or the Duchi
+//            extension (README.md:27-35).
+//   finalize loss assembly and the relative-change stop rule on device (_solver.py:162-174).
+//
+// Layout in HBM: Y is packed once into MFMA accumulator order, 16x16 tiles, one
+// byte per entry on the binary path ({ym, zero-observed, valid} bits) or one double per entry,
+// in two sweep orders (strip-major for each pass) so every wave streams contiguous memory.
+// Factors are kept in natural [k][len] order plus two operand-ordered copies ("T": Theta operand,
+// "G": gradient/back-product operand) so LDS staging is a linear copy and ds_reads are lane-linear.
+//
+// No BLAS, no PyTorch: plain HIP + (optionally, loaded at run time) RCCL.
+
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nbmf_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(NBMF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,  \
+                  __LINE__);                                                                      \
+  } while (0)
+
+inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+enum { DATA_BIN = 0, DATA_F64 = 1, DATA_F64M = 2 };
+enum { MODE_H = 0, MODE_W = 1 };
+
+// code bits of the binary path
+enum : unsigned { CB_YM = 1u, CB_ZOBS = 2u, CB_VALID = 4u };
+
+constexpr int PAD = 128;          // m and n are padded to multiples of 128 (8 row blocks, 8 strips)
+constexpr int WG_WAVES = 4;       // waves (= column strips) per workgroup of the pass kernel
+constexpr int STAGE_BYTES = 32768; // LDS per workgroup: NB row blocks x (T + G operand images)
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+// Reciprocal of d in [eps, 1+eps]: hardware seed + two Newton steps (<= 1 ulp; no scaling needed in
+// this range).  Stands in for the IEEE divides of _solver.py:42-43,53 on the binary path, where the
+// numerator is exactly 0 or 1.
+__device__ __forceinline__ double rcp_nr(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  // fixed butterfly order -> bitwise reproducible
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// The fused pass kernel.
+//   D      data matrix of this pass, R row blocks x C column strips of 16x16 tiles
+//   L      the factor indexed by D's rows (streamed through LDS):  LT = Theta operand, LG = back operand
+//   Rf     the factor indexed by D's columns (stationary in registers, T form)
+//   MODE_H: out1 = L (R1), out2 = L (R2)                  (P1, P2 of _solver.py:42-43)
+//   MODE_W: out1 = L (S1 - S2) + column sums of S2         (the bracket of _solver.py:53)
+// Workgroup = 4 waves; wave w owns column strip 4*blockIdx.x + w and sweeps row blocks
+// [chunk*CH, chunk*CH + CH).  Partial results go to per-chunk slabs (ordered reduction later: no
+// atomics, bitwise reproducible).
+// ------------------------------------------------------------------------------------------
+struct PassArgs {
+  const void* data;     // BIN: uint32 [C strips][Rb][64] ; F64: double [C strips][Rb][64][4]
+  const void* mask;     // F64M only, same indexing as data
+  const double* LT;     // [Rb][K/4][64]
+  const double* LG;     // [Rb][K/16][4][64]
+  const double* RfT;    // [Cb][K/4][64]
+  double* out1;         // [chunks][K][C_alloc]
+  double* out2;         // MODE_H only
+  double* lossbuf;      // MODE_H: [chunks][Cb] per-wave log-likelihood partials
+  const int* done;      // device stop flag: skip all work when set
+  int Rb;               // row blocks of D (multiple of 8)
+  int Cb;               // column strips of D (multiple of 4)
+  int CH;               // row blocks per chunk (multiple of NB)
+  long long C_alloc;    // 16*Cb
+  double eps;
+};
+
+template <int KB, int DATA, int MODE>
+__global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a) {
+  constexpr int K = 16 * KB;
+  constexpr int S = K / 4;            // Theta k-steps
+  constexpr int NB = 8 / KB;          // row blocks per LDS stage
+  constexpr int BLK = K * 16;         // doubles per block per operand image
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // [NB][T image | G image]
+
+  if (*a.done) return;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int cb = blockIdx.x * WG_WAVES + wave;
+  const int chunk = blockIdx.y;
+  const int rb0 = chunk * a.CH;
+  const int rb1 = min(rb0 + a.CH, a.Rb);
+  const double eps = a.eps;
+
+  // stationary operand: Rf in T form for this strip
+  double rf[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) rf[s] = a.RfT[((size_t)cb * S + s) * 64 + lane];
+
+  d4 acc1[KB], acc2[KB];
+#pragma unroll
+  for (int i = 0; i < KB; ++i) {
+    acc1[i] = d4{0, 0, 0, 0};
+    acc2[i] = d4{0, 0, 0, 0};
+  }
+  double prod = 1.0;   // BIN loss: running product of the per-entry Bernoulli probabilities
+  int pexp = 0;        //           and its binary exponent
+  double llsum = 0.0;  // F64 loss
+  double s2 = 0.0;     // MODE_W: column sums of S2
+
+  const uint32_t* codes = (const uint32_t*)a.data + (size_t)cb * a.Rb * 64 + lane;
+  const d4* yv = (const d4*)a.data + (size_t)cb * a.Rb * 64 + lane;
+  const d4* mv = (const d4*)a.mask + (size_t)cb * a.Rb * 64 + lane;
+
+  for (int rb = rb0; rb < rb1; rb += NB) {
+    __syncthreads();   // everyone is done reading the previous stage
+    {
+      // linear copy of NB blocks of each operand image into LDS (16 B per thread per step)
+      const double2* srcT = (const double2*)(a.LT + (size_t)rb * BLK);
+      const double2* srcG = (const double2*)(a.LG + (size_t)rb * BLK);
+      double2* dst = (double2*)lds;
+      constexpr int N2 = NB * BLK / 2;   // double2 per image per stage (= 1024)
+#pragma unroll
+      for (int u = 0; u < N2 / 256; ++u) {
+        dst[u * 256 + threadIdx.x] = srcT[u * 256 + threadIdx.x];
+        dst[N2 + u * 256 + threadIdx.x] = srcG[u * 256 + threadIdx.x];
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const double* ldsT = lds + b * BLK;
+      const double* ldsG = lds + NB * BLK + b * BLK;
+
+      // ---- Theta tile: rows 16(rb+b)+4r+q, column 16cb+c in register r of lane (q,c)
+      d4 th = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < S; ++s) th = __builtin_amdgcn_mfma_f64_16x16x4f64(ldsT[s * 64 + lane], rf[s], th, 0, 0, 0);
+
+      // ---- ratios
+      double R1[4], R2[4];
+      if (DATA == DATA_BIN) {
+        const uint32_t code = codes[(size_t)(rb + b) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t cbits = code >> (8 * r);
+          const bool ym = cbits & CB_YM;
+          const double t = th[r];
+          const double d = ym ? (t + eps) : ((1.0 - t) + eps);
+          const double rr = rcp_nr(d);
+          if (MODE == MODE_H) {
+            const bool valid = cbits & CB_VALID;
+            R1[r] = ym ? rr : 0.0;
+            R2[r] = (valid && !ym) ? rr : 0.0;
+            prod *= valid ? d : 1.0;
+          } else {
+            const bool zo = cbits & CB_ZOBS;
+            R1[r] = ym ? rr : (zo ? -rr : 0.0);   // S1 - S2
+            s2 += zo ? rr : 0.0;
+          }
+        }
+        if (MODE == MODE_H) {
+          int e;
+          prod = frexp(prod, &e);
+          pexp += e;
+        }
+      } else {
+        const d4 y4 = yv[(size_t)(rb + b) * 64];
+        d4 m4 = {1, 1, 1, 1};
+        if (DATA == DATA_F64M) m4 = mv[(size_t)(rb + b) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double y = y4[r];
+          const bool valid = y >= 0.0;    // pad entries are stored as -1
+          const double t = th[r];
+          const double t1 = t + eps;
+          const double t2 = (1.0 - t) + eps;
+          if (MODE == MODE_H) {
+            const double ym = (DATA == DATA_F64M) ? y * m4[r] : y;    // Y*mask, _solver.py:30
+            R1[r] = valid ? ym / t1 : 0.0;                            // :42
+            R2[r] = valid ? (1.0 - ym) / t2 : 0.0;                    // :43 (1 - Y*mask)
+            llsum += valid ? (ym * log(t1) + (1.0 - ym) * log(t2)) : 0.0;   // :150,154
+          } else {
+            const double yo = (DATA == DATA_F64M) ? y * m4[r] : y;                 // Y.T*mask.T, :31
+            const double zo = (DATA == DATA_F64M) ? (1.0 - y) * m4[r] : (1.0 - y);  // (1-Y).T*mask.T, :32
+            const double s1v = valid ? yo / t1 : 0.0;
+            const double s2v = valid ? zo / t2 : 0.0;
+            R1[r] = s1v - s2v;
+            s2 += s2v;
+          }
+        }
+      }
+
+      // ---- back-products: accumulator registers of Theta are the B operands (rows 4r..4r+3)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const double g = ldsG[(kb * 4 + r) * 64 + lane];
+          acc1[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(g, R1[r], acc1[kb], 0, 0, 0);
+          if (MODE == MODE_H) acc2[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(g, R2[r], acc2[kb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: slabs [chunk][k][column]
+  const int q = lane >> 4, c = lane & 15;
+  if (MODE == MODE_W) {
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+  }
+  double* o1 = a.out1 + (size_t)chunk * K * a.C_alloc + (size_t)cb * 16 + c;
+  double* o2 = (MODE == MODE_H) ? a.out2 + (size_t)chunk * K * a.C_alloc + (size_t)cb * 16 + c : nullptr;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t k = 16 * kb + 4 * r + q;
+      if (MODE == MODE_H) {
+        o1[k * a.C_alloc] = acc1[kb][r];
+        o2[k * a.C_alloc] = acc2[kb][r];
+      } else {
+        o1[k * a.C_alloc] = acc1[kb][r] + s2;
+      }
+    }
+  }
+  if (MODE == MODE_H) {
+    double ll;
+    if (DATA == DATA_BIN)
+      ll = log(prod) + (double)pexp * 0.6931471805599453094;
+    else
+      ll = llsum;
+    ll = wave_sum(ll);
+    if (lane == 0) a.lossbuf[(size_t)chunk * a.Cb + cb] = ll;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Ordered reduction of the H-pass slabs: Pbuf[t][k][j] = sum_chunks slab[t][chunk][k][j], and the
+// log-likelihood partials -> Pbuf tail.  (In multi-GPU runs Pbuf is what RCCL all-reduces.)
+// ------------------------------------------------------------------------------------------
+__global__ void reduce_h_kernel(const double* __restrict__ slab1, const double* __restrict__ slab2,
+                                const double* __restrict__ lossbuf, double* __restrict__ Pbuf, int chunks,
+                                long long per /* K_pad * nA */, int n_loss, const int* done) {
+  if (*done) return;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < per) {
+    double s1 = 0, s2 = 0;
+    for (int ch = 0; ch < chunks; ++ch) {
+      s1 += slab1[(size_t)ch * per + i];
+      s2 += slab2[(size_t)ch * per + i];
+    }
+    Pbuf[i] = s1;
+    Pbuf[per + i] = s2;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    double s = 0;
+    for (int j = threadIdx.x; j < n_loss; j += 64) s += lossbuf[j];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) Pbuf[2 * per] = s;
+  }
+}
+
+// Beta log-prior sums of H (natural layout), per-block partials -> prior[blk][2] (_solver.py:158-159).
+__device__ __forceinline__ void block_sum2(double a, double b, double* out2) {
+  __shared__ double sh[2][8];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][w] = a;
+    sh[1][w] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double x = 0, y = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+      x += sh[0][i];
+      y += sh[1][i];
+    }
+    out2[0] = x;
+    out2[1] = y;
+  }
+}
+
+// H-update (_solver.py:42-47) from the reduced products; writes natural, T and G forms.
+// One thread per (k, j); j fastest.
+__global__ __launch_bounds__(256) void h_update_kernel(const double* __restrict__ Pbuf, double* __restrict__ Hn,
+                                                       double* __restrict__ HT, double* __restrict__ HG,
+                                                       double* __restrict__ prior, int K, int KP, long long n,
+                                                       long long nA, double am1, double bm1, double eps,
+                                                       const int* done) {
+  if (*done) return;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long k = idx / nA, j = idx % nA;
+  double la = 0, lb = 0;
+  if (k < KP) {
+    double h = 0.0;
+    if (k < K && j < n) {
+      const double hold = Hn[idx];
+      const double num = hold * Pbuf[idx] + am1;                             // :42
+      const double den = (1.0 - hold) * Pbuf[(size_t)KP * nA + idx] + bm1;   // :43
+      h = num / (num + den + eps);                                           // :46
+      h = fmin(fmax(h, eps), 1.0 - eps);                                     // :47
+      la = log(h + eps);                                                     // :158
+      lb = log(1.0 - h + eps);                                               // :159
+    }
+    Hn[idx] = h;
+    const long long jb = j >> 4, c = j & 15;
+    HT[(jb * KP + k) * 16 + c] = h;
+    HG[jb * KP * 16 + (k >> 4) * 256 + c * 16 + (k & 15)] = h;
+  }
+  block_sum2(la, lb, prior + 2 * (size_t)blockIdx.x);
+}
+
+// Prior sums only (used after nbmf_set_factors).
+__global__ __launch_bounds__(256) void prior_kernel(const double* __restrict__ Hn, double* __restrict__ prior, int K,
+                                                    int KP, long long n, long long nA, double eps) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long k = idx / nA, j = idx % nA;
+  double la = 0, lb = 0;
+  if (k < K && j < n) {
+    const double h = Hn[idx];
+    la = log(h + eps);
+    lb = log(1.0 - h + eps);
+  }
+  block_sum2(la, lb, prior + 2 * (size_t)blockIdx.x);
+}
+
+// Loss assembly + stop rule (_solver.py:158-175), one wave.
+//   scal[0] = previous loss, flags[0] = done, flags[1] = n_iter
+__global__ void finalize_kernel(const double* __restrict__ Pbuf, long long ll_index, const double* __restrict__ prior,
+                                int n_prior, double am1, double bm1, double n_obs, double* __restrict__ losses,
+                                int t, double tol, double* __restrict__ scal, int* __restrict__ flags) {
+  if (flags[0]) return;
+  double sa = 0, sb = 0;
+  for (int i = threadIdx.x; i < n_prior; i += 64) {
+    sa += prior[2 * i];
+    sb += prior[2 * i + 1];
+  }
+  sa = wave_sum(sa);
+  sb = wave_sum(sb);
+  if (threadIdx.x == 0) {
+    const double ll = Pbuf[ll_index];
+    const double A = am1 * sa;
+    const double B = bm1 * sb;
+    const double loss = -(ll + A + B) / n_obs;   // :162
+    losses[t] = loss;
+    flags[1] = t + 1;
+    if (t > 0) {
+      const double prev = scal[0];
+      if (fabs(prev - loss) / fabs(prev) < tol) flags[0] = 1;   // :169-174
+    }
+    scal[0] = loss;
+  }
+}
+
+// W-update (_solver.py:53-57): thread per column i.  Q = sum over chunks of the W-pass slabs.
+// projection 0: (W*Q)/n then divide by the column sum.  projection 1 (extension): (W*Q)/count_i then
+// Euclidean projection onto the simplex (Michelot active-set iteration; unique minimiser).
+__global__ __launch_bounds__(256) void w_update_kernel(const double* __restrict__ slab, int chunks, double* __restrict__ Wn,
+                                                       double* __restrict__ WT, double* __restrict__ WG, int K, int KP,
+                                                       long long m, long long mA, double n_div,
+                                                       const double* __restrict__ rowcnt, int projection,
+                                                       const int* done) {
+  if (*done) return;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mA) return;
+  const size_t per = (size_t)KP * mA;
+  const long long ib = i >> 4, c = i & 15;
+  if (i >= m) {
+    for (int k = 0; k < KP; ++k) {
+      Wn[(size_t)k * mA + i] = 0.0;
+      WT[(ib * KP + k) * 16 + c] = 0.0;
+      WG[ib * KP * 16 + (k >> 4) * 256 + c * 16 + (k & 15)] = 0.0;
+    }
+    return;
+  }
+  const double div = (projection == NBMF_PROJ_DUCHI && rowcnt) ? fmax(rowcnt[i], 1.0) : n_div;
+  double sum = 0.0;
+  for (int k = 0; k < K; ++k) {
+    double qv = 0.0;
+    for (int ch = 0; ch < chunks; ++ch) qv += slab[(size_t)ch * per + (size_t)k * mA + i];
+    const double w = (Wn[(size_t)k * mA + i] * qv) / div;   // :53-54
+    Wn[(size_t)k * mA + i] = w;                              // staged in place (own column only)
+    sum += w;
+  }
+  double tau = 0.0, scale = 1.0;
+  if (projection == NBMF_PROJ_DUCHI) {
+    // Michelot: tau = (sum_{active} v - 1)/|active|, drop v <= tau, repeat until stable.
+    tau = (sum - 1.0) / K;
+    int cnt = K;
+    for (int it = 0; it < K; ++it) {
+      double s = 0.0;
+      int c2 = 0;
+      for (int k = 0; k < K; ++k) {
+        const double v = Wn[(size_t)k * mA + i];
+        if (v > tau) {
+          s += v;
+          ++c2;
+        }
+      }
+      if (c2 == 0) break;
+      const double t2 = (s - 1.0) / c2;
+      const bool same = (c2 == cnt);
+      tau = t2;
+      cnt = c2;
+      if (same) break;
+    }
+  } else {
+    scale = sum;
+  }
+  for (int k = 0; k < KP; ++k) {
+    double w = 0.0;
+    if (k < K) {
+      const double v = Wn[(size_t)k * mA + i];
+      w = (projection == NBMF_PROJ_DUCHI) ? fmax(v - tau, 0.0) : v / scale;   // :57
+    }
+    Wn[(size_t)k * mA + i] = w;
+    WT[(ib * KP + k) * 16 + c] = w;
+    WG[ib * KP * 16 + (k >> 4) * 256 + c * 16 + (k & 15)] = w;
+  }
+}
+
+// Factor upload: natural true-size [K][len] (staging) -> padded natural, T, G.
+__global__ void set_factor_kernel(const double* __restrict__ src, double* __restrict__ Fn, double* __restrict__ FT,
+                                  double* __restrict__ FG, int K, int KP, long long len, long long lenA) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)KP * lenA) return;
+  const long long k = idx / lenA, x = idx % lenA;
+  const double v = (k < K && x < len) ? src[k * len + x] : 0.0;
+  Fn[idx] = v;
+  const long long xb = x >> 4, c = x & 15;
+  FT[(xb * KP + k) * 16 + c] = v;
+  FG[xb * KP * 16 + (k >> 4) * 256 + c * 16 + (k & 15)] = v;
+}
+
+__global__ void get_factor_kernel(const double* __restrict__ Fn, double* __restrict__ dst, int K, long long len,
+                                  long long lenA) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)K * len) return;
+  const long long k = idx / len, x = idx % len;
+  dst[idx] = Fn[k * lenA + x];
+}
+
+// ------------------------------------------------------------------------------------------
+// Pack kernel: raw row-major chunk of the user's matrix -> the two tile-ordered images.
+// One wave per 16x16 tile of the user's matrix X (rows u, columns v).
+//   transposed = 0: Y = X   (i = u, j = v);   transposed = 1: Y = X^T (i = v, j = u).
+//   image A (H-pass): [strip over j][block over i][lane (q,c)][r] = Y[16ib+4r+q][16jb+c]
+//   image B (W-pass): [strip over i][block over j][lane (q,c)][r] = Y[16ib+c][16jb+4r+q]
+// stats[0] = count of observed (mask != 0) in-range entries, stats[1] = #entries outside [0,1] or
+// non-finite, stats[2] = #non-binary data entries, stats[3] = #non-binary mask entries.
+// ------------------------------------------------------------------------------------------
+struct PackArgs {
+  const double* x;        // chunk base: rows [u0, u0+urows) of X
+  const void* mask;       // same chunk of the mask or nullptr
+  int mask_kind;
+  long long ldx, ldmask;  // elements
+  long long u0, urows;    // chunk row range in X
+  long long U, V;         // X dims
+  int transposed;
+  int binary;             // 1: write byte codes, 0: write doubles (+ mask doubles)
+  void *dataA, *dataB, *maskA, *maskB;
+  long long RbA, RbB;     // row blocks of image A (= mA/16) and of image B (= nA/16)
+  unsigned long long* stats;
+  double* rowcnt;         // unused here (filled by rowcount kernel)
+};
+
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+  __shared__ double tv[4][16][17];
+  __shared__ double tm[4][16][17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  const long long vb = (long long)blockIdx.x * 4 + wave;            // tile column in X
+  const long long ub = a.u0 / 16 + blockIdx.y;                      // tile row in X
+  unsigned long long n_obs = 0, n_bad = 0, n_nonbin = 0, n_mnonbin = 0;
+  // load style "A": element (row 4r+q, col c) of the X tile
+  double va[4], ma[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long u = ub * 16 + 4 * r + q, v = vb * 16 + c;
+    double x = -1.0, mk = 0.0;
+    if (u < a.U && u < a.u0 + a.urows && v < a.V) {
+      x = a.x[(u - a.u0) * a.ldx + v];
+      mk = 1.0;
+      if (a.mask_kind == NBMF_MASK_F64) mk = ((const double*)a.mask)[(u - a.u0) * a.ldmask + v];
+      if (a.mask_kind == NBMF_MASK_U8) mk = ((const unsigned char*)a.mask)[(u - a.u0) * a.ldmask + v] ? 1.0 : 0.0;
+      if (!(x >= 0.0 && x <= 1.0)) ++n_bad;
+      if (x != 0.0 && x != 1.0) ++n_nonbin;
+      if (mk != 0.0 && mk != 1.0) ++n_mnonbin;
+      if (mk != 0.0) ++n_obs;
+    }
+    va[r] = x;
+    ma[r] = mk;
+    tv[wave][4 * r + q][c] = x;
+    tm[wave][4 * r + q][c] = mk;
+  }
+  __syncthreads();
+  // style "B": element (row c, col 4r+q)
+  double vbv[4], mbv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    vbv[r] = tv[wave][c][4 * r + q];
+    mbv[r] = tm[wave][c][4 * r + q];
+  }
+  // which style feeds which image
+  const double* forA_v = a.transposed ? vbv : va;
+  const double* forA_m = a.transposed ? mbv : ma;
+  const double* forB_v = a.transposed ? va : vbv;
+  const double* forB_m = a.transposed ? ma : mbv;
+  // tile coordinates in Y: ib (block over i), jb (block over j)
+  const long long ib = a.transposed ? vb : ub;
+  const long long jb = a.transposed ? ub : vb;
+  if (ib < a.RbA && jb < a.RbB) {
+    const size_t ia = ((size_t)jb * a.RbA + ib) * 64 + lane;   // image A: strip jb, block ib
+    const size_t ibx = ((size_t)ib * a.RbB + jb) * 64 + lane;  // image B: strip ib, block jb
+    if (a.binary) {
+      uint32_t ca = 0, cbb = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        {
+          const double x = forA_v[r], mk = forA_m[r];
+          uint32_t code = 0;
+          if (x >= 0.0) code = CB_VALID | ((x != 0.0 && mk != 0.0) ? CB_YM : 0u) | ((x == 0.0 && mk != 0.0) ? CB_ZOBS : 0u);
+          ca |= code << (8 * r);
+        }
+        {
+          const double x = forB_v[r], mk = forB_m[r];
+          uint32_t code = 0;
+          if (x >= 0.0) code = CB_VALID | ((x != 0.0 && mk != 0.0) ? CB_YM : 0u) | ((x == 0.0 && mk != 0.0) ? CB_ZOBS : 0u);
+          cbb |= code << (8 * r);
+        }
+      }
+      ((uint32_t*)a.dataA)[ia] = ca;
+      ((uint32_t*)a.dataB)[ibx] = cbb;
+    } else {
+      ((d4*)a.dataA)[ia] = d4{forA_v[0], forA_v[1], forA_v[2], forA_v[3]};
+      ((d4*)a.dataB)[ibx] = d4{forB_v[0], forB_v[1], forB_v[2], forB_v[3]};
+      if (a.mask_kind != NBMF_MASK_NONE) {
+        ((d4*)a.maskA)[ia] = d4{forA_m[0], forA_m[1], forA_m[2], forA_m[3]};
+        ((d4*)a.maskB)[ibx] = d4{forB_m[0], forB_m[1], forB_m[2], forB_m[3]};
+      }
+    }
+  }
+  // integer statistics (order-independent)
+  for (int off = 32; off >= 1; off >>= 1) {
+    n_obs += __shfl_xor(n_obs, off, 64);
+    n_bad += __shfl_xor(n_bad, off, 64);
+    n_nonbin += __shfl_xor(n_nonbin, off, 64);
+    n_mnonbin += __shfl_xor(n_mnonbin, off, 64);
+  }
+  if (lane == 0) {
+    if (n_obs) atomicAdd(&a.stats[0], n_obs);
+    if (n_bad) atomicAdd(&a.stats[1], n_bad);
+    if (n_nonbin) atomicAdd(&a.stats[2], n_nonbin);
+    if (n_mnonbin) atomicAdd(&a.stats[3], n_mnonbin);
+  }
+}
+
+// Per-internal-row observed weight (Duchi extension, README.md:32-35): thread per internal row i,
+// walking image B (strip ib, blocks over j) in order -> deterministic.
+__global__ void rowcount_kernel(const void* dataB, const void* maskB, int data_kind, long long RbB, long long m,
+                                double* rowcnt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const long long ib = i >> 4;
+  const int c = i & 15;
+  double s = 0.0;
+  for (long long jb = 0; jb < RbB; ++jb) {
+    for (int qq = 0; qq < 4; ++qq) {
+      const size_t base = ((size_t)ib * RbB + jb) * 64 + qq * 16 + c;
+      if (data_kind == DATA_BIN) {
+        const uint32_t code = ((const uint32_t*)dataB)[base];
+        for (int r = 0; r < 4; ++r) s += ((code >> (8 * r)) & (CB_YM | CB_ZOBS)) ? 1.0 : 0.0;
+      } else {
+        const d4 y = ((const d4*)dataB)[base];
+        d4 mk = {1, 1, 1, 1};
+        if (data_kind == DATA_F64M) mk = ((const d4*)maskB)[base];
+        for (int r = 0; r < 4; ++r) s += (y[r] >= 0.0) ? mk[r] : 0.0;
+      }
+    }
+  }
+  rowcnt[i] = s;
+}
+
+__global__ void rcp_test_kernel(double* out, int n, double eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // log-uniform-ish sweep of [eps, 1+eps]
+  const double u = (i + 0.5) / n;
+  const double d = exp(log(eps) * (1.0 - u)) * (1.0 + 1e-3 * (i % 7)) + eps;
+  const double dd = fmin(d, 1.0 + eps);
+  const double ref = 1.0 / dd;
+  out[i] = fabs(rcp_nr(dd) - ref) / ref;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct nbmf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t m = 0, n = 0, mA = 0, nA = 0;
+  int k = 0, KP = 0, KB = 0;
+  int data_kind = -1;   // -1 = nothing uploaded
+  void *dataA = nullptr, *dataB = nullptr, *maskA = nullptr, *maskB = nullptr;
+  double n_obs = 0, n_obs_global = 0;
+  double* rowcnt = nullptr;
+  double *Wn = nullptr, *WT = nullptr, *WG = nullptr, *Hn = nullptr, *HT = nullptr, *HG = nullptr;
+  bool have_factors = false;
+  int chunksH = 0, CH_H = 0, chunksW = 0, CH_W = 0;
+  double *slabH = nullptr, *slabW = nullptr, *Pbuf = nullptr, *lossbuf = nullptr, *prior = nullptr, *scal = nullptr;
+  int n_prior_blocks = 0;
+  int* flags = nullptr;
+  double* losses_d = nullptr;
+  int losses_cap = 0;
+  double* stage = nullptr;   // host->device staging for factors
+  size_t stage_bytes = 0;
+  unsigned long long* stats = nullptr;
+  double alpha = 1.2, beta = 1.2, eps = 1e-8;
+  int projection = NBMF_PROJ_NORMALIZE;
+  // comm
+  void* comm = nullptr;
+  int nranks = 1, rank = 0;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev;   // pairs
+  std::vector<int> ev_kind;     // 0 = H-pass, 1 = W-pass
+  size_t ev_used = 0;
+  double t_ms[2] = {0, 0};
+  int t_n[2] = {0, 0};
+};
+
+namespace {
+
+// ---- RCCL, loaded lazily so that single-GPU use has no dependency on it ---------------------
+struct Uid {
+  char internal[128];
+};
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, /*ncclUniqueId by value*/ Uid, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.lib) return NBMF_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* lib = nullptr;
+  for (const char* nm : names) {
+    lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(NBMF_ERR_COMM, "cannot load librccl: %s", dlerror());
+  g_rccl.GetUniqueId = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, Uid, int))dlsym(lib, "ncclCommInitRank");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    return fail(NBMF_ERR_COMM, "librccl is missing expected symbols");
+  g_rccl.lib = lib;
+  return NBMF_OK;
+}
+constexpr int kNcclFloat64 = 8;   // ncclDouble (rccl.h ncclDataType_t)
+constexpr int kNcclSum = 0;       // ncclSum
+
+#define NCCLCHK(call)                                                                                     \
+  do {                                                                                                    \
+    int r_ = (call);                                                                                      \
+    if (r_ != 0)                                                                                          \
+      return fail(NBMF_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+  } while (0)
+
+// ---- pass launch ----------------------------------------------------------------------------
+template <int KB, int DATA, int MODE>
+hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
+  dim3 grid(a.Cb / WG_WAVES, chunks);
+  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE>), grid, dim3(256), STAGE_BYTES, st, a);
+  return hipGetLastError();
+}
+
+template <int DATA, int MODE>
+hipError_t launch_pass_kb(int KB, const PassArgs& a, int chunks, hipStream_t st) {
+  switch (KB) {
+    case 1: return launch_pass_t<1, DATA, MODE>(a, chunks, st);
+    case 2: return launch_pass_t<2, DATA, MODE>(a, chunks, st);
+    case 4: return launch_pass_t<4, DATA, MODE>(a, chunks, st);
+    case 8: return launch_pass_t<8, DATA, MODE>(a, chunks, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <int MODE>
+hipError_t launch_pass(int KB, int data_kind, const PassArgs& a, int chunks, hipStream_t st) {
+  switch (data_kind) {
+    case DATA_BIN: return launch_pass_kb<DATA_BIN, MODE>(KB, a, chunks, st);
+    case DATA_F64: return launch_pass_kb<DATA_F64, MODE>(KB, a, chunks, st);
+    case DATA_F64M: return launch_pass_kb<DATA_F64M, MODE>(KB, a, chunks, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+void pick_chunks(int strips_groups, int Rb, int NB, int* chunks, int* CH) {
+  // aim for >= ~2048 workgroups (256 CUs x 2 resident x 4 rounds) without making chunks tiny
+  int want = (2048 + strips_groups - 1) / strips_groups;
+  int max_chunks = Rb / NB;
+  if (want > max_chunks) want = max_chunks;
+  if (want < 1) want = 1;
+  int ch = (Rb + want - 1) / want;
+  ch = (int)round_up(ch, NB);
+  *CH = ch;
+  *chunks = (Rb + ch - 1) / ch;
+}
+
+struct EvScope {
+  nbmf_ctx* c;
+  int kind;
+  size_t slot = (size_t)-1;
+  EvScope(nbmf_ctx* c_, int kind_) : c(c_), kind(kind_) {
+    if (!c->timing) return;
+    if (c->ev_used + 2 > c->ev.size()) {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->ev.push_back(e);
+      }
+      c->ev_kind.push_back(kind);
+    } else {
+      c->ev_kind[c->ev_used / 2] = kind;
+    }
+    slot = c->ev_used;
+    c->ev_used += 2;
+    hipEventRecord(c->ev[slot], c->stream);
+  }
+  ~EvScope() {
+    if (slot != (size_t)-1) hipEventRecord(c->ev[slot + 1], c->stream);
+  }
+};
+
+void timing_collect(nbmf_ctx* c) {
+  // caller has synchronised the stream
+  for (size_t s = 0; s + 1 < c->ev_used; s += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev[s], c->ev[s + 1]) == hipSuccess) {
+      c->t_ms[c->ev_kind[s / 2]] += ms;
+      c->t_n[c->ev_kind[s / 2]] += 1;
+    }
+  }
+  c->ev_used = 0;
+}
+
+int enqueue_h_pass(nbmf_ctx* c) {
+  PassArgs a{};
+  a.data = c->dataA;
+  a.mask = c->maskA;
+  a.LT = c->WT;
+  a.LG = c->WG;
+  a.RfT = c->HT;
+  a.out1 = c->slabH;
+  a.out2 = c->slabH + (size_t)c->chunksH * c->KP * c->nA;
+  a.lossbuf = c->lossbuf;
+  a.done = c->flags;
+  a.Rb = (int)(c->mA / 16);
+  a.Cb = (int)(c->nA / 16);
+  a.CH = c->CH_H;
+  a.C_alloc = c->nA;
+  a.eps = c->eps;
+  {
+    EvScope ev(c, 0);
+    HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
+  }
+  const long long per = (long long)c->KP * c->nA;
+  hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, a.out1, a.out2,
+                     c->lossbuf, c->Pbuf, c->chunksH, per, c->chunksH * a.Cb, c->flags);
+  HIPCHK(hipGetLastError());
+  if (c->comm) {
+    NCCLCHK(g_rccl.AllReduce(c->Pbuf, c->Pbuf, (size_t)(2 * per + 1), kNcclFloat64, kNcclSum, c->comm, c->stream));
+  }
+  return NBMF_OK;
+}
+
+int enqueue_finalize(nbmf_ctx* c, int t, double tol) {
+  const long long per = (long long)c->KP * c->nA;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, c->stream, c->Pbuf, 2 * per, c->prior, c->n_prior_blocks,
+                     c->alpha - 1.0, c->beta - 1.0, c->n_obs_global, c->losses_d, t, tol, c->scal, c->flags);
+  HIPCHK(hipGetLastError());
+  return NBMF_OK;
+}
+
+int enqueue_h_update(nbmf_ctx* c) {
+  hipLaunchKernelGGL(h_update_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Pbuf, c->Hn, c->HT, c->HG,
+                     c->prior, c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps,
+                     c->flags);
+  HIPCHK(hipGetLastError());
+  return NBMF_OK;
+}
+
+int enqueue_w_step(nbmf_ctx* c, int projection) {
+  PassArgs a{};
+  a.data = c->dataB;
+  a.mask = c->maskB;
+  a.LT = c->HT;
+  a.LG = c->HG;
+  a.RfT = c->WT;
+  a.out1 = c->slabW;
+  a.out2 = nullptr;
+  a.lossbuf = nullptr;
+  a.done = c->flags;
+  a.Rb = (int)(c->nA / 16);
+  a.Cb = (int)(c->mA / 16);
+  a.CH = c->CH_W;
+  a.C_alloc = c->mA;
+  a.eps = c->eps;
+  {
+    EvScope ev(c, 1);
+    HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, a, c->chunksW, c->stream));
+  }
+  hipLaunchKernelGGL(w_update_kernel, dim3((unsigned)((c->mA + 255) / 256)), dim3(256), 0, c->stream, c->slabW,
+                     c->chunksW, c->Wn, c->WT, c->WG, c->k, c->KP, (long long)c->m, (long long)c->mA, (double)c->n,
+                     c->rowcnt, projection, c->flags);
+  HIPCHK(hipGetLastError());
+  return NBMF_OK;
+}
+
+int ensure_losses(nbmf_ctx* c, int cap) {
+  if (cap <= c->losses_cap) return NBMF_OK;
+  if (c->losses_d) HIPCHK(hipFree(c->losses_d));
+  c->losses_d = nullptr;
+  HIPCHK(hipMalloc(&c->losses_d, sizeof(double) * (size_t)cap));
+  c->losses_cap = cap;
+  return NBMF_OK;
+}
+
+int ready(nbmf_ctx* c) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "nbmf_upload has not been called");
+  if (!c->have_factors) return fail(NBMF_ERR_STATE, "nbmf_set_factors has not been called");
+  return NBMF_OK;
+}
+
+int set_device(nbmf_ctx* c) {
+  HIPCHK(hipSetDevice(c->device));
+  return NBMF_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int nbmf_abi_version(void) { return 1; }
+
+const char* nbmf_last_error(void) { return g_err.c_str(); }
+
+int nbmf_device_count(int* count) {
+  if (!count) return fail(NBMF_ERR_ARG, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(NBMF_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return NBMF_OK;
+}
+
+int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
+  if (!out) return fail(NBMF_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (m < 1 || n < 1) return fail(NBMF_ERR_ARG, "m and n must be >= 1 (got %lld x %lld)", (long long)m, (long long)n);
+  if (k < 1 || k > NBMF_MAX_K) return fail(NBMF_ERR_ARG, "n_components must be in [1, %d] (got %d)", NBMF_MAX_K, k);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1)
+    return fail(NBMF_ERR_HIP, "no HIP device available (%s): libnbmf_hip needs an MI355X (gfx950)",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(NBMF_ERR_ARG, "device %d out of range (have %d)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NBMF_ERR_HIP, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+
+  nbmf_ctx* c = new nbmf_ctx();
+  c->device = device;
+  c->m = m;
+  c->n = n;
+  c->k = k;
+  c->mA = round_up(m, PAD);
+  c->nA = round_up(n, PAD);
+  c->KB = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
+  c->KP = 16 * c->KB;
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+  const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
+  HIPCHK(hipMalloc(&c->Wn, fw));
+  HIPCHK(hipMalloc(&c->WT, fw));
+  HIPCHK(hipMalloc(&c->WG, fw));
+  HIPCHK(hipMalloc(&c->Hn, fh));
+  HIPCHK(hipMalloc(&c->HT, fh));
+  HIPCHK(hipMalloc(&c->HG, fh));
+  const int NB = 8 / c->KB;
+  pick_chunks((int)(c->nA / 16 / WG_WAVES), (int)(c->mA / 16), NB, &c->chunksH, &c->CH_H);
+  pick_chunks((int)(c->mA / 16 / WG_WAVES), (int)(c->nA / 16), NB, &c->chunksW, &c->CH_W);
+  HIPCHK(hipMalloc(&c->slabH, 2 * (size_t)c->chunksH * fh));
+  HIPCHK(hipMalloc(&c->slabW, (size_t)c->chunksW * fw));
+  HIPCHK(hipMalloc(&c->Pbuf, 2 * fh + 64));
+  HIPCHK(hipMalloc(&c->lossbuf, sizeof(double) * (size_t)c->chunksH * (c->nA / 16)));
+  c->n_prior_blocks = (int)(((size_t)c->KP * c->nA + 255) / 256);
+  HIPCHK(hipMalloc(&c->prior, sizeof(double) * 2 * (size_t)c->n_prior_blocks));
+  HIPCHK(hipMalloc(&c->scal, sizeof(double) * 8));
+  HIPCHK(hipMalloc(&c->flags, sizeof(int) * 8));
+  HIPCHK(hipMalloc(&c->stats, sizeof(unsigned long long) * 8));
+  HIPCHK(hipMalloc(&c->rowcnt, sizeof(double) * (size_t)c->mA));
+  HIPCHK(hipMemset(c->flags, 0, sizeof(int) * 8));
+  HIPCHK(hipMemset(c->scal, 0, sizeof(double) * 8));
+  c->stage_bytes = (fw > fh ? fw : fh);
+  HIPCHK(hipMalloc(&c->stage, c->stage_bytes));
+  *out = c;
+  return NBMF_OK;
+}
+
+int nbmf_destroy(nbmf_ctx* c) {
+  if (!c) return NBMF_OK;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
+                  c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  for (hipEvent_t e : c->ev) hipEventDestroy(e);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return NBMF_OK;
+}
+
+int nbmf_set_hyper(nbmf_ctx* c, double alpha, double beta, double eps, int projection) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (projection != NBMF_PROJ_NORMALIZE && projection != NBMF_PROJ_DUCHI)
+    return fail(NBMF_ERR_ARG, "unknown projection %d", projection);
+  if (!(eps > 0)) return fail(NBMF_ERR_ARG, "eps must be > 0");
+  c->alpha = alpha;
+  c->beta = beta;
+  c->eps = eps;
+  c->projection = projection;
+  return NBMF_OK;
+}
+
+int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const void* mask, int mask_kind,
+                int64_t ldmask, int* out_flags) {
+  if (!c || !x) return fail(NBMF_ERR_ARG, "null context or data");
+  if (mask_kind != NBMF_MASK_NONE && !mask) return fail(NBMF_ERR_ARG, "mask_kind set but mask is NULL");
+  if (!mask) mask_kind = NBMF_MASK_NONE;
+  if (int rc = set_device(c)) return rc;
+  const int64_t U = transposed ? c->n : c->m, V = transposed ? c->m : c->n;
+  if (ldx < V || (mask && ldmask < V)) return fail(NBMF_ERR_ARG, "leading dimension smaller than the row length");
+
+  // cheap host-side guess of the storage path from a sample (the device pack verifies it exactly)
+  bool guess_bin = true;
+  {
+    const int64_t rows = U < 8 ? U : 8;
+    for (int64_t u = 0; u < rows && guess_bin; ++u) {
+      const int64_t uu = (U - 1) * u / (rows > 1 ? rows - 1 : 1);
+      for (int64_t v = 0; v < V && v < 4096; ++v) {
+        const double xv = x[uu * ldx + v];
+        if (xv != 0.0 && xv != 1.0) {
+          guess_bin = false;
+          break;
+        }
+        if (mask_kind == NBMF_MASK_F64) {
+          const double mk = ((const double*)mask)[uu * ldmask + v];
+          if (mk != 0.0 && mk != 1.0) {
+            guess_bin = false;
+            break;
+          }
+        }
+      }
+    }
+  }
+
+  const size_t tiles = (size_t)(c->mA / 16) * (c->nA / 16);
+  const int64_t chunk_rows_max = std::max<int64_t>(PAD, ((int64_t)(256ll << 20) / (V * 8)) / PAD * PAD);
+  double* raw = nullptr;
+  void* rawm = nullptr;
+  const size_t msz = mask_kind == NBMF_MASK_F64 ? 8 : 1;
+  const int64_t chunk_rows = std::min<int64_t>(round_up(U, PAD), chunk_rows_max);
+  HIPCHK(hipMalloc(&raw, (size_t)chunk_rows * V * 8));
+  if (mask) HIPCHK(hipMalloc(&rawm, (size_t)chunk_rows * V * msz));
+
+  int rc = NBMF_OK;
+  unsigned long long st[4] = {0, 0, 0, 0};
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool binary = (attempt == 0) ? guess_bin : false;
+    for (void** p : {&c->dataA, &c->dataB, &c->maskA, &c->maskB}) {
+      if (*p) hipFree(*p);
+      *p = nullptr;
+    }
+    c->data_kind = -1;
+    const size_t esz = binary ? 1 : 8;
+    const size_t bytes = tiles * 256 * esz;
+    HIPCHK(hipMalloc(&c->dataA, bytes));
+    HIPCHK(hipMalloc(&c->dataB, bytes));
+    // pad tiles must read as "invalid": code 0 on the binary path, -1.0 on the f64 path
+    // (the pack kernel writes every tile of the padded mA x nA grid; out-of-range lanes get the
+    //  "invalid" marker: code 0 on the binary path, -1.0 on the f64 path)
+    if (!binary && mask_kind != NBMF_MASK_NONE) {
+      HIPCHK(hipMalloc(&c->maskA, bytes));
+      HIPCHK(hipMalloc(&c->maskB, bytes));
+    }
+    HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
+
+    for (int64_t u0 = 0; u0 < round_up(U, PAD); u0 += chunk_rows) {
+      const int64_t urows_pad = std::min<int64_t>(chunk_rows, round_up(U, PAD) - u0);
+      const int64_t urows = std::max<int64_t>(0, std::min<int64_t>(U - u0, urows_pad));
+      if (urows > 0) {
+        HIPCHK(hipMemcpy2DAsync(raw, (size_t)V * 8, x + u0 * ldx, (size_t)ldx * 8, (size_t)V * 8, (size_t)urows,
+                                hipMemcpyHostToDevice, c->stream));
+        if (mask)
+          HIPCHK(hipMemcpy2DAsync(rawm, (size_t)V * msz, (const char*)mask + (size_t)u0 * ldmask * msz,
+                                  (size_t)ldmask * msz, (size_t)V * msz, (size_t)urows, hipMemcpyHostToDevice,
+                                  c->stream));
+      }
+      PackArgs a{};
+      a.x = raw;
+      a.mask = mask ? rawm : nullptr;
+      a.mask_kind = mask_kind;
+      a.ldx = V;
+      a.ldmask = V;
+      a.u0 = u0;
+      a.urows = urows;
+      a.U = U;
+      a.V = V;
+      a.transposed = transposed;
+      a.binary = binary ? 1 : 0;
+      a.dataA = c->dataA;
+      a.dataB = c->dataB;
+      a.maskA = c->maskA;
+      a.maskB = c->maskB;
+      a.RbA = c->mA / 16;
+      a.RbB = c->nA / 16;
+      a.stats = c->stats;
+      const int64_t VA = transposed ? c->mA : c->nA;
+      dim3 grid((unsigned)(VA / 16 / 4), (unsigned)(urows_pad / 16));
+      hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, c->stream, a);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(c->stream));   // raw staging buffer is reused by the next chunk
+    }
+    HIPCHK(hipMemcpy(st, c->stats, sizeof st, hipMemcpyDeviceToHost));
+    if (st[1] != 0) {
+      rc = fail(NBMF_ERR_RANGE, "X must be binary: %llu entries outside [0,1] or not finite", st[1]);
+      break;
+    }
+    const bool is_bin = (st[2] == 0 && st[3] == 0);
+    if (binary && !is_bin) continue;   // sample guessed wrong: repack as doubles
+    c->data_kind = binary ? DATA_BIN : (mask_kind != NBMF_MASK_NONE ? DATA_F64M : DATA_F64);
+    break;
+  }
+  hipFree(raw);
+  if (rawm) hipFree(rawm);
+  if (rc != NBMF_OK) return rc;
+  if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "internal: pack did not settle on a storage path");
+  c->n_obs = (mask_kind == NBMF_MASK_NONE) ? (double)c->m * (double)c->n : (double)st[0];
+  c->n_obs_global = c->n_obs;
+  hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
+                     c->data_kind, (long long)(c->nA / 16), (long long)c->m, c->rowcnt);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (out_flags) *out_flags = (c->data_kind == DATA_BIN) ? NBMF_FLAG_BINARY_PATH : 0;
+  return NBMF_OK;
+}
+
+int nbmf_get_n_obs(nbmf_ctx* c, double* n_obs) {
+  if (!c || !n_obs) return fail(NBMF_ERR_ARG, "null argument");
+  if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "nbmf_upload has not been called");
+  *n_obs = c->n_obs;
+  return NBMF_OK;
+}
+
+int nbmf_set_factors(nbmf_ctx* c, const double* W, const double* H) {
+  if (!c || !W || !H) return fail(NBMF_ERR_ARG, "null argument");
+  if (int rc = set_device(c)) return rc;
+  HIPCHK(hipMemcpyAsync(c->stage, W, sizeof(double) * (size_t)c->k * c->m, hipMemcpyHostToDevice, c->stream));
+  {
+    const long long tot = (long long)c->KP * c->mA;
+    hipLaunchKernelGGL(set_factor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->stage, c->Wn,
+                       c->WT, c->WG, c->k, c->KP, (long long)c->m, (long long)c->mA);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyAsync(c->stage, H, sizeof(double) * (size_t)c->k * c->n, hipMemcpyHostToDevice, c->stream));
+  {
+    const long long tot = (long long)c->KP * c->nA;
+    hipLaunchKernelGGL(set_factor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->stage, c->Hn,
+                       c->HT, c->HG, c->k, c->KP, (long long)c->n, (long long)c->nA);
+    HIPCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(prior_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Hn, c->prior, c->k, c->KP,
+                     (long long)c->n, (long long)c->nA, c->eps);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->have_factors = true;
+  return NBMF_OK;
+}
+
+int nbmf_get_factors(nbmf_ctx* c, double* W, double* H) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (!c->have_factors) return fail(NBMF_ERR_STATE, "no factors on the device");
+  if (int rc = set_device(c)) return rc;
+  if (W) {
+    const long long tot = (long long)c->k * c->m;
+    hipLaunchKernelGGL(get_factor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->Wn, c->stage,
+                       c->k, (long long)c->m, (long long)c->mA);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(W, c->stage, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  if (H) {
+    const long long tot = (long long)c->k * c->n;
+    hipLaunchKernelGGL(get_factor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->Hn, c->stage,
+                       c->k, (long long)c->n, (long long)c->nA);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(H, c->stage, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return NBMF_OK;
+}
+
+int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter) {
+  if (int rc = ready(c)) return rc;
+  if (max_iter < 1) return fail(NBMF_ERR_ARG, "max_iter must be >= 1");
+  if (!losses || !n_iter) return fail(NBMF_ERR_ARG, "null output");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_losses(c, max_iter)) return rc;
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->scal, 0, sizeof(double) * 8, c->stream));
+
+  // Timeline (N3 of SURVEY Appendix A): the H-pass of iteration t also yields the log-likelihood of
+  // the factors after iteration t-1, so loss(t-1) and its stop test are settled before H-update(t).
+  const int batch = (tol > 0.0) ? 8 : max_iter;
+  int host_done = 0;
+  int it = 0;
+  while (it < max_iter && !host_done) {
+    const int end = std::min(max_iter, it + batch);
+    for (; it < end; ++it) {
+      if (int rc = enqueue_h_pass(c)) return rc;
+      if (it > 0)
+        if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;
+      if (int rc = enqueue_h_update(c)) return rc;
+      if (int rc = enqueue_w_step(c, c->projection)) return rc;
+    }
+    if (tol > 0.0 && it < max_iter) {
+      int fl[2];
+      HIPCHK(hipMemcpyAsync(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->timing) timing_collect(c);
+      host_done = fl[0];
+    }
+  }
+  if (!host_done) {
+    if (int rc = enqueue_h_pass(c)) return rc;                    // loss of the last iteration
+    if (int rc = enqueue_finalize(c, max_iter - 1, tol)) return rc;
+  }
+  int fl[2];
+  HIPCHK(hipMemcpyAsync(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->timing) timing_collect(c);
+  const int nit = fl[1];
+  if (nit < 1 || nit > max_iter) return fail(NBMF_ERR_STATE, "internal: device reported n_iter=%d", nit);
+  HIPCHK(hipMemcpy(losses, c->losses_d, sizeof(double) * (size_t)nit, hipMemcpyDeviceToHost));
+  *n_iter = nit;
+  return NBMF_OK;
+}
+
+int nbmf_w_only_steps(nbmf_ctx* c, int n_steps) {
+  if (int rc = ready(c)) return rc;
+  if (n_steps < 0) return fail(NBMF_ERR_ARG, "n_steps must be >= 0");
+  if (int rc = set_device(c)) return rc;
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
+  for (int s = 0; s < n_steps; ++s)
+    if (int rc = enqueue_w_step(c, NBMF_PROJ_NORMALIZE)) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->timing) timing_collect(c);
+  return NBMF_OK;
+}
+
+int nbmf_loss(nbmf_ctx* c, double* loss) {
+  if (int rc = ready(c)) return rc;
+  if (!loss) return fail(NBMF_ERR_ARG, "null output");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_losses(c, 1)) return rc;
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
+  hipLaunchKernelGGL(prior_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Hn, c->prior, c->k, c->KP,
+                     (long long)c->n, (long long)c->nA, c->eps);
+  HIPCHK(hipGetLastError());
+  if (int rc = enqueue_h_pass(c)) return rc;
+  if (int rc = enqueue_finalize(c, 0, 0.0)) return rc;
+  HIPCHK(hipMemcpyAsync(loss, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->timing) timing_collect(c);
+  return NBMF_OK;
+}
+
+int nbmf_comm_unique_id(void* id128) {
+  if (!id128) return fail(NBMF_ERR_ARG, "null id");
+  if (int rc = load_rccl()) return rc;
+  NCCLCHK(g_rccl.GetUniqueId(id128));
+  return NBMF_OK;
+}
+
+int nbmf_comm_init(nbmf_ctx* c, const void* id128, int nranks, int rank) {
+  if (!c || !id128) return fail(NBMF_ERR_ARG, "null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(NBMF_ERR_ARG, "bad rank %d / nranks %d", rank, nranks);
+  if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "call nbmf_upload before nbmf_comm_init (the observed count is reduced here)");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = load_rccl()) return rc;
+  Uid uid;
+  memcpy(uid.internal, id128, 128);
+  NCCLCHK(g_rccl.CommInitRank(&c->comm, nranks, uid, rank));
+  c->nranks = nranks;
+  c->rank = rank;
+  // global observed count (the divisor of _solver.py:162)
+  HIPCHK(hipMemcpyAsync(c->scal + 4, &c->n_obs, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  NCCLCHK(g_rccl.AllReduce(c->scal + 4, c->scal + 4, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
+  HIPCHK(hipMemcpyAsync(&c->n_obs_global, c->scal + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NBMF_OK;
+}
+
+int nbmf_timing_enable(nbmf_ctx* c, int enable) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  c->timing = enable != 0;
+  c->ev_used = 0;
+  c->t_ms[0] = c->t_ms[1] = 0;
+  c->t_n[0] = c->t_n[1] = 0;
+  return NBMF_OK;
+}
+
+int nbmf_timing_get(nbmf_ctx* c, double* hpass_ms, int* hpass_launches, double* wpass_ms, int* wpass_launches) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (hpass_ms) *hpass_ms = c->t_ms[0];
+  if (hpass_launches) *hpass_launches = c->t_n[0];
+  if (wpass_ms) *wpass_ms = c->t_ms[1];
+  if (wpass_launches) *wpass_launches = c->t_n[1];
+  return NBMF_OK;
+}
+
+int nbmf_synchronize(nbmf_ctx* c) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (int rc = set_device(c)) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NBMF_OK;
+}
+
+int nbmf_selftest_rcp(int device, int n, double* max_rel_err) {
+  if (!max_rel_err || n < 1) return fail(NBMF_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  double* d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(double) * (size_t)n));
+  hipLaunchKernelGGL(rcp_test_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d, n, 1e-8);
+  HIPCHK(hipGetLastError());
+  std::vector<double> h((size_t)n);
+  HIPCHK(hipMemcpy(h.data(), d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  hipFree(d);
+  double mx = 0;
+  for (double v : h) mx = v > mx ? v : mx;
+  *max_rel_err = mx;
+  return NBMF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,240 @@
+"""GPU parity: libnbmf_hip (through the C ABI) against the CPU oracle and the reference's golden
+vectors, same seeded inputs.  Tolerances: loss curve <= 1e-10 relative per point,
+factors <= 1e-9 absolute, final NLL <= 1e-8 relative (north star), monotone within 1e-12.
+"""
+import numpy as np
+import pytest
+
+from conftest import config1_X, config1_mask, midsize_XM
+from oracle import nbmf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-10
+FACTOR_ATOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from nbmf_mm_amd import _hip
+    assert _hip.device_count() >= 1, "no MI355X visible: the GPU tests must run on the GPU box"
+    return _hip
+
+
+def _one_step(hip, Y, W, H, mask, al, be, projection=0):
+    k, m = W.shape
+    n = H.shape[1]
+    with hip.Context(m, n, k) as ctx:
+        ctx.set_hyper(al, be, 1e-8, projection)
+        ctx.upload(Y, mask=mask)
+        ctx.set_factors(W, H)
+        losses, n_iter = ctx.run(1, 0.0)
+        Wn, Hn = ctx.get_factors()
+        return Wn, Hn, losses[0], ctx.binary_path
+
+
+def test_reciprocal_accuracy(hip):
+    # Newton reciprocal used on the binary path: <= 1 ulp over the denominator range [eps, 1+eps]
+    assert hip.selftest_rcp(1 << 20) <= 2.3e-16
+
+
+def test_one_step_golden_vectors(hip, golden):
+    g = golden("one_step")
+    for i in range(int(g["n_cases"])):
+        p = f"c{i}_"
+        mask = g[p + "mask"]
+        mask = None if mask.size == 0 else mask
+        al, be = g[p + "ab"]
+        Wn, Hn, loss, binpath = _one_step(hip, g[p + "Y"], g[p + "W"], g[p + "H"], mask, al, be)
+        np.testing.assert_allclose(Hn, g[p + "H_new"], rtol=0, atol=1e-13, err_msg=f"case {i} H")
+        np.testing.assert_allclose(Wn, g[p + "W_new"], rtol=0, atol=1e-13, err_msg=f"case {i} W")
+        ref_loss = orc.mm_loss(g[p + "Y"], g[p + "W_new"], g[p + "H_new"], mask, al, be)
+        assert abs(loss - ref_loss) <= 1e-12 * abs(ref_loss), f"case {i} loss"
+        assert binpath == (i < 18)          # the last vector is real-valued with a weight mask
+
+
+def test_config1_curve(hip, golden):
+    from nbmf_mm_amd import NBMF
+    g = golden("config1")
+    mdl = NBMF(n_components=6, orientation="beta-dir", alpha=1.2, beta=1.2, random_state=0,
+               max_iter=200, tol=0).fit(config1_X())
+    np.testing.assert_allclose(mdl.loss_curve_, g["losses"], rtol=LOSS_RTOL, atol=0)
+    np.testing.assert_allclose(mdl.W_, g["W"], rtol=0, atol=FACTOR_ATOL)
+    np.testing.assert_allclose(mdl.components_, g["H"], rtol=0, atol=FACTOR_ATOL)
+    assert mdl.n_iter_ == 200 and len(mdl.loss_curve_) == 200
+    # default stop rule: same iteration count and loss as the reference
+    mdl = NBMF(n_components=6, random_state=0).fit(config1_X())
+    assert mdl.n_iter_ == int(g["default_n_iter"])
+    assert abs(mdl.loss_ - float(g["default_loss"])) <= 1e-10 * float(g["default_loss"])
+
+
+def test_dir_beta(hip, golden):
+    from nbmf_mm_amd import NBMF
+    g = golden("dir_beta")
+    X = config1_X()
+    mdl = NBMF(n_components=6, orientation="dir-beta", random_state=0, max_iter=50, tol=0).fit(X)
+    np.testing.assert_allclose(mdl.loss_curve_, g["losses"], rtol=LOSS_RTOL, atol=0)
+    np.testing.assert_allclose(mdl.W_, g["W"], rtol=0, atol=FACTOR_ATOL)
+    np.testing.assert_allclose(mdl.components_, g["H"], rtol=0, atol=FACTOR_ATOL)
+    # the transpose identity is bitwise: dir-beta(X).W_ == beta-dir(X.T).components_.T
+    mdlT = NBMF(n_components=6, orientation="beta-dir", random_state=0, max_iter=50, tol=0).fit(X.T)
+    np.testing.assert_array_equal(mdl.W_, mdlT.components_.T)
+    np.testing.assert_array_equal(mdl.loss_curve_, mdlT.loss_curve_)
+
+
+def test_masked_float_and_bool(hip, golden):
+    from nbmf_mm_amd import NBMF
+    g = golden("masked")
+    X, mask = config1_X(), config1_mask()
+    curves = []
+    for mk, key in [(mask.astype(np.float64), "losses_float"), (mask, "losses_bool")]:
+        mdl = NBMF(n_components=6, random_state=0, max_iter=100, tol=0).fit(X, mask=mk)
+        np.testing.assert_allclose(mdl.loss_curve_, g[key], rtol=LOSS_RTOL, atol=0)
+        curves.append(np.array(mdl.loss_curve_))
+    np.testing.assert_array_equal(curves[0], curves[1])
+    np.testing.assert_allclose(mdl.W_, g["W"], rtol=0, atol=FACTOR_ATOL)
+    l = curves[0]
+    assert all(l[i] <= l[i - 1] + 1e-12 for i in range(1, len(l)))
+
+
+def test_real_valued(hip, golden):
+    from nbmf_mm_amd import NBMF
+    g = golden("real_valued")
+    Xr = np.random.default_rng(3).random((50, 30))
+    mdl = NBMF(n_components=5, random_state=1, max_iter=30, tol=0).fit(Xr)
+    np.testing.assert_allclose(mdl.loss_curve_, g["losses"], rtol=LOSS_RTOL, atol=0)
+    np.testing.assert_allclose(mdl.W_, g["W"], rtol=0, atol=FACTOR_ATOL)
+    np.testing.assert_allclose(mdl.components_, g["H"], rtol=0, atol=FACTOR_ATOL)
+
+
+def test_custom_init_both_orientations(hip, golden):
+    from nbmf_mm_amd import NBMF
+    g = golden("custom_init")
+    mdl = NBMF(n_components=4, random_state=123, max_iter=50, tol=1e-8, W_init=g["W0"], H_init=g["H0"]).fit(g["Y"])
+    assert mdl.n_iter_ == int(g["n_iter"])
+    np.testing.assert_allclose(mdl.loss_curve_, g["losses"], rtol=LOSS_RTOL, atol=0)
+    np.testing.assert_allclose(mdl.W_, g["W"], rtol=0, atol=FACTOR_ATOL)
+    mdl = NBMF(n_components=4, orientation="dir-beta", random_state=123, max_iter=20, tol=0,
+               W_init=g["Wd0"], H_init=g["Hd0"]).fit(g["Y"])
+    np.testing.assert_allclose(mdl.loss_curve_, g["d_losses"], rtol=LOSS_RTOL, atol=0)
+    np.testing.assert_allclose(mdl.W_, g["dW"], rtol=0, atol=FACTOR_ATOL)
+    np.testing.assert_allclose(mdl.components_, g["dH"], rtol=0, atol=FACTOR_ATOL)
+    with pytest.raises(ValueError):     # only one init under dir-beta on non-square V
+        NBMF(n_components=4, orientation="dir-beta", max_iter=2, W_init=g["Wd0"]).fit(g["Y"])
+
+
+def test_stop_rule_counts(hip, golden):
+    from nbmf_mm_amd import NBMF
+    g = golden("stop_rule")
+    hi = NBMF(n_components=5, tol=0.1, max_iter=1000, random_state=42).fit(g["X"])
+    lo = NBMF(n_components=5, tol=1e-8, max_iter=1000, random_state=42).fit(g["X"])
+    assert hi.n_iter_ == int(g["n_iter_hi"]) and lo.n_iter_ == int(g["n_iter_lo"])
+    assert len(lo.loss_curve_) == lo.n_iter_
+    np.testing.assert_allclose(lo.loss_curve_, g["losses_lo"], rtol=LOSS_RTOL, atol=0)
+
+
+def test_transform_score_perplexity(hip, golden):
+    from nbmf_mm_amd import NBMF
+    g = golden("transform")
+    X, mask = config1_X(), config1_mask()
+    mdl = NBMF(n_components=6, random_state=0, max_iter=60, tol=0).fit(X, mask=mask)
+    np.testing.assert_allclose(mdl.components_, g["H"], rtol=0, atol=FACTOR_ATOL)
+    mdl.components_ = g["H"]            # continue from the reference's H so only transform is compared
+    Xn = (np.random.default_rng(9).random((10, 500)) < 0.25).astype(np.float64)
+    np.random.seed(5)
+    np.testing.assert_allclose(mdl.transform(Xn), g["W_new"], rtol=0, atol=FACTOR_ATOL)
+    np.random.seed(5)
+    np.testing.assert_allclose(mdl.transform(X, mask=mask.astype(np.float64)), g["W_masked"], rtol=0, atol=FACTOR_ATOL)
+    np.random.seed(6)
+    sc = mdl.score(X, mask=mask.astype(np.float64))
+    assert abs(sc - float(g["score"])) <= 1e-10 * abs(float(g["score"]))
+    np.random.seed(6)
+    assert abs(mdl.perplexity(X, mask=mask.astype(np.float64)) - float(g["perplexity"])) <= 1e-10 * float(g["perplexity"])
+    assert isinstance(sc, float)
+
+
+def test_midsize_curves(hip, golden):
+    """512x512 (K=32, 500 its), masked (300 its), dir-beta masked K=64, real-valued weighted K=16."""
+    from nbmf_mm_amd import nbmf_mm_solver
+    g = golden("midsize")
+    X, M = midsize_XM()
+    _, _, l, t, n_it = nbmf_mm_solver(X, 32, max_iter=500, tol=0, random_state=0)
+    assert t == 0.0 and n_it == 500
+    np.testing.assert_allclose(l, g["unmasked"], rtol=LOSS_RTOL, atol=0)
+    assert abs(l[-1] - 0.5264565431072413) <= 1e-10
+    _, _, l, _, _ = nbmf_mm_solver(X, 32, max_iter=300, tol=0, random_state=0, mask=M)
+    np.testing.assert_allclose(l, g["masked"], rtol=LOSS_RTOL, atol=0)
+    assert all(l[i] <= l[i - 1] + 1e-12 for i in range(1, len(l)))
+    _, _, l, _, _ = nbmf_mm_solver(X[:, :384], 64, max_iter=100, tol=0, random_state=0, orientation="dir-beta",
+                                   mask=M[:, :384])
+    np.testing.assert_allclose(l, g["dir_beta_masked"], rtol=LOSS_RTOL, atol=0)
+    g2 = np.random.default_rng(4)
+    Xrv, Wts = g2.random((300, 200)), g2.random((300, 200))
+    _, _, l, _, _ = nbmf_mm_solver(Xrv, 16, max_iter=60, tol=0, random_state=2, mask=Wts)
+    np.testing.assert_allclose(l, g["real_weighted"], rtol=LOSS_RTOL, atol=0)
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (17, 5, 3), (130, 257, 17), (200, 129, 33), (64, 300, 100),
+                                   (129, 128, 128), (16, 16, 16)])
+def test_ragged_shapes_vs_oracle(hip, m, n, k):
+    """Edge shapes: not multiples of the 16x16 tile or the 128 padding; every K template."""
+    r = np.random.default_rng(m * 1000 + n)
+    Y = (r.random((m, n)) < 0.4).astype(np.float64)
+    mask = (r.random((m, n)) < 0.85) if (m + n) % 2 else None
+    W0 = r.uniform(0.1, 0.9, (m, k))
+    H0 = r.uniform(0.1, 0.9, (k, n))
+    from nbmf_mm_amd import nbmf_mm_solver
+    W, H, l, _, _ = nbmf_mm_solver(Y, k, max_iter=12, tol=0, W_init=W0, H_init=H0, mask=mask, alpha=1.3, beta=1.1)
+    Wr, Hr, lr, _, _ = orc.solve(Y, k, max_iter=12, tol=0, W_init=W0, H_init=H0, mask=mask, alpha=1.3, beta=1.1)
+    np.testing.assert_allclose(l, lr, rtol=LOSS_RTOL, atol=0)
+    np.testing.assert_allclose(W, Wr, rtol=0, atol=FACTOR_ATOL)
+    np.testing.assert_allclose(H, Hr, rtol=0, atol=FACTOR_ATOL)
+
+
+def test_bitwise_run_to_run(hip):
+    from nbmf_mm_amd import NBMF
+    X, M = midsize_XM()
+    a = NBMF(n_components=32, random_state=7, max_iter=40, tol=0).fit(X[:300, :411], mask=M[:300, :411])
+    b = NBMF(n_components=32, random_state=7, max_iter=40, tol=0).fit(X[:300, :411], mask=M[:300, :411])
+    np.testing.assert_array_equal(a.components_, b.components_)
+    np.testing.assert_array_equal(a.W_, b.W_)
+    np.testing.assert_array_equal(a.loss_curve_, b.loss_curve_)
+
+
+def test_duchi_extension_properties(hip):
+    """projection='duchi' (README.md:27-35; parity unpinned): simplex exact, tracks the CPU
+    restatement of the same extension, near-identical to 'normalize' when unmasked."""
+    from nbmf_mm_amd import NBMF
+    X, mask = config1_X(), config1_mask()
+    d = NBMF(n_components=6, random_state=0, max_iter=40, tol=0, projection="duchi").fit(X, mask=mask)
+    np.testing.assert_allclose(d.W_.sum(axis=1), 1.0, atol=1e-12)
+    assert (d.W_ >= 0).all()
+    _, _, lr, _, _ = orc.solve(X, 6, max_iter=40, tol=0, random_state=0, mask=mask, step=orc.mm_step_duchi)
+    np.testing.assert_allclose(d.loss_curve_, lr, rtol=1e-9, atol=0)
+    nrm = NBMF(n_components=6, random_state=0, max_iter=40, tol=0).fit(X)
+    du = NBMF(n_components=6, random_state=0, max_iter=40, tol=0, projection_method="duchi").fit(X)
+    np.testing.assert_allclose(du.loss_curve_, nrm.loss_curve_, rtol=1e-6)
+
+
+def test_loss_entry_point_matches_oracle(hip):
+    r = np.random.default_rng(5)
+    Y = (r.random((90, 70)) < 0.3).astype(np.float64)
+    W = r.uniform(0.1, 0.9, (7, 90)); W /= W.sum(axis=0, keepdims=True)
+    H = r.uniform(0.1, 0.9, (7, 70))
+    with hip.Context(90, 70, 7) as ctx:
+        ctx.set_hyper(1.4, 1.1)
+        ctx.upload(Y)
+        ctx.set_factors(W, H)
+        got = ctx.loss()
+        assert ctx.n_obs() == 90 * 70
+    want = orc.mm_loss(Y, W, H, None, 1.4, 1.1)
+    assert abs(got - want) <= 1e-12 * abs(want)
+
+
+def test_out_of_range_raises(hip):
+    from nbmf_mm_amd import NBMF
+    with pytest.raises(ValueError, match="must be binary"):
+        NBMF(n_components=3, max_iter=2).fit(np.random.default_rng(0).normal(size=(20, 10)))
+    with pytest.raises(ValueError):
+        from nbmf_mm_amd import nbmf_mm_solver
+        nbmf_mm_solver(np.full((20, 10), 1.5), 3, max_iter=2)       # solver-level range check is on the device
