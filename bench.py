@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MM-iterations/sec of the NBMF-MM inner loop on MI355X.
+
+Workload (BASELINE.json metric / configs[2]): synthetic dense binary V 65536 x 8192 handed over as
+float64, K=64, mask with 90 % observed entries, alpha=beta=1.2, eps=1e-8, tol=0 (fixed iteration
+count).  One "step" = one MM iteration = H-step + W-step + loss (src/nbmf_mm/_solver.py:143-175 of
+the reference).  With --gpus N the SAME V is row-sharded over N ranks (strong scaling); every
+iteration all-reduces the K x N H-step products over RCCL.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run (one rank per GPU).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet fp64 matrix = 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
+                               # (measured back-to-back v_mfma_f64_16x16x4_f64: 71.5 TFLOP/s)
+
+
+def make_shard(M, N, r0, r1, seed, density=0.25, observed=0.9, masked=True):
+    """Rows [r0, r1) of the synthetic V / mask.  Generated per 4096-row block from
+    default_rng([seed, block]) so that any sharding sees the same global matrix."""
+    X = np.empty((r1 - r0, N), dtype=np.float64)
+    Mk = np.empty((r1 - r0, N), dtype=np.bool_) if masked else None
+    BLK = 4096
+    for b in range(r0 // BLK, (r1 + BLK - 1) // BLK):
+        lo, hi = max(r0, b * BLK), min(r1, (b + 1) * BLK)
+        g = np.random.default_rng([seed, b])
+        blk = g.random((min(BLK, M - b * BLK), N))
+        X[lo - r0:hi - r0] = blk[lo - b * BLK:hi - b * BLK] < density
+        if masked:
+            blk = g.random((min(BLK, M - b * BLK), N))
+            Mk[lo - r0:hi - r0] = blk[lo - b * BLK:hi - b * BLK] < observed
+    return X, Mk
+
+
+def init_factors(M, N, K, seed):
+    """Reference init rule (_solver.py:102-136): global RNG, W (M,K) then H (K,N), column-normalise W."""
+    np.random.seed(seed)
+    W0 = np.random.uniform(0.1, 0.9, (M, K))
+    H0 = np.random.uniform(0.1, 0.9, (K, N))
+    W = W0.T / W0.T.sum(axis=0, keepdims=True)
+    return np.ascontiguousarray(W), H0
+
+
+def cpu_baseline(N, K, seed, masked, budget_rows=2048, iters=3):
+    """The CPU oracle (NumPy port of the reference iteration) timed on this host on a bounded
+    sample: the first `budget_rows` rows of the same V; cost is linear in M at fixed N, K."""
+    from oracle import nbmf_oracle as orc
+    try:
+        import threadpoolctl
+        info = threadpoolctl.threadpool_info()
+        threads = max([d.get("num_threads", 1) for d in info] or [1])
+    except Exception:
+        threads = len(os.sched_getaffinity(0))
+    X, Mk = make_shard(budget_rows, N, 0, budget_rows, seed, masked=masked)
+    mask = Mk.astype(np.float64) if masked else None
+    W, H = init_factors(budget_rows, N, K, seed)
+    W, H = orc.mm_step(X, W, H, mask, 1.2, 1.2)            # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        W, H = orc.mm_step(X, W, H, mask, 1.2, 1.2)
+        loss = orc.mm_loss(X, W, H, mask, 1.2, 1.2)
+    dt = (time.perf_counter() - t0) / iters
+    return dt, threads, float(loss)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--M", type=int, default=65536)
+    ap.add_argument("--N", type=int, default=8192)
+    ap.add_argument("--K", type=int, default=64)
+    ap.add_argument("--no-mask", action="store_true")
+    ap.add_argument("--projection", default="duchi", choices=["normalize", "duchi"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+
+    import torch            # plumbing only: rendezvous (gloo), barrier, max-over-ranks; no compute
+    import torch.distributed as dist
+    from nbmf_mm_amd import _hip
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    M, N, K = args.M, args.N, args.K
+    masked = not args.no_mask
+    rows = (M + world - 1) // world
+    rows = (rows + 127) // 128 * 128                      # shard boundaries on the 128-row padding unit
+    r0, r1 = min(M, rank * rows), min(M, (rank + 1) * rows)
+
+    X, Mk = make_shard(M, N, r0, r1, args.seed, masked=masked)
+    W_full, H0 = init_factors(M, N, K, args.seed)
+    ctx = _hip.Context(r1 - r0, N, K, device=local_rank)
+    ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_DUCHI if args.projection == "duchi" else _hip.PROJ_NORMALIZE)
+    t_up = time.perf_counter()
+    binary_path = ctx.upload(X, mask=Mk)
+    t_up = time.perf_counter() - t_up
+    bytes_up = X.nbytes + (Mk.nbytes if masked else 0)
+    del X, Mk
+    ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
+    if world > 1:
+        uid = [_hip.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], world, rank)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize() if torch.cuda.is_available() and torch.cuda.is_initialized() else None
+        if world > 1:
+            dist.barrier()
+
+    if args.warmup > 0:
+        ctx.run(args.warmup, 0.0)
+    ctx.timing_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    losses, n_iter = ctx.run(args.steps, 0.0)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    sync()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tim = ctx.timing()
+    ctx.close()
+
+    if rank == 0:
+        its = args.steps / dt
+        m_loc = r1 - r0
+        h_ms = tim["hpass_ms"] / max(1, tim["hpass_launches"])
+        w_ms = tim["wpass_ms"] / max(1, tim["wpass_launches"])
+        # algorithmic flop of one H-pass launch: Theta + two back-products = 6*m*N*K
+        flop_pass = 6.0 * m_loc * N * K
+        achieved = flop_pass / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
+        out = {
+            "metric": "MM-iterations/sec", "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "final_nll_per_entry": float(losses[-1]),
+            "loss_monotone": bool(all(losses[i] <= losses[i - 1] + 1e-12 for i in range(1, len(losses)))),
+            "config": {"workload": f"NBMF-MM fit, dense binary V {M}x{N} (float64 API, density 0.25), K={K}, "
+                                   f"{'mask 90% observed' if masked else 'no mask'}, projection={args.projection}, "
+                                   f"alpha=beta=1.2, tol=0 (BASELINE.json configs[2])",
+                       "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
+                       "sharding": f"rows/{world}" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
+                         "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "hpass_ms": h_ms, "wpass_ms": w_ms,
+                         "iteration_frac": (12.0 * m_loc * N * K * its / 1e12) / PEAK_FP64_MFMA_TFLOPS},
+            "upload": {"seconds": t_up, "GBps_pcie_inclusive": bytes_up / t_up / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample_rows = 2048
+            cdt, threads, closs = cpu_baseline(N, K, args.seed, masked, sample_rows, 3)
+            out["cpu_baseline"] = {"value": 1.0 / (cdt * M / sample_rows), "unit": "it/s", "cores": threads,
+                                   "kind": "port",
+                                   "sample": f"oracle/nbmf_oracle.py (NumPy+OpenBLAS) on the first {sample_rows} rows x {N} cols, "
+                                             f"3 iterations after 1 warm-up = {cdt:.2f} s/it, scaled x{M // sample_rows} to {M} rows "
+                                             f"(cost is linear in M)",
+                                   "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+            out["speedup_vs_cpu"] = its / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
