@@ -71,7 +71,7 @@ enum : unsigned { CB_YM = 1u, CB_ZOBS = 2u, CB_VALID = 4u };
 
 constexpr int PAD = 128;          // m and n are padded to multiples of 128 (8 row blocks, 8 strips)
 constexpr int WG_WAVES = 4;       // waves (= column strips) per workgroup of the pass kernel
-constexpr int STAGE_BYTES = 32768; // LDS per workgroup: NB row blocks x (T + G operand images)
+constexpr int STAGE_BYTES = 32768; // one LDS stage: NB row blocks x (T + G operand images); two stages per workgroup
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
   constexpr int S = K / 4;            // Theta k-steps
   constexpr int NB = 8 / KB;          // row blocks per LDS stage
   constexpr int BLK = K * 16;         // doubles per block per operand image
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // [NB][T image | G image]
+  constexpr int STAGE_D = 2 * NB * BLK;   // doubles per stage: [NB][T image] then [NB][G image] (= 32 KB)
+  constexpr int N2 = NB * BLK / 2;    // double2 per image per stage (= 1024)
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // two stages (double buffer)
 
   if (*a.done) return;
 
@@ -161,36 +163,89 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
   const d4* yv = (const d4*)a.data + (size_t)cb * a.Rb * 64 + lane;
   const d4* mv = (const d4*)a.mask + (size_t)cb * a.Rb * 64 + lane;
 
-  for (int rb = rb0; rb < rb1; rb += NB) {
-    __syncthreads();   // everyone is done reading the previous stage
-    {
-      // linear copy of NB blocks of each operand image into LDS (16 B per thread per step)
-      const double2* srcT = (const double2*)(a.LT + (size_t)rb * BLK);
-      const double2* srcG = (const double2*)(a.LG + (size_t)rb * BLK);
-      double2* dst = (double2*)lds;
-      constexpr int N2 = NB * BLK / 2;   // double2 per image per stage (= 1024)
+  // ---- staging: the operand images of NB row blocks are contiguous in HBM in exactly the LDS order,
+  //      so a stage is a linear 2 x 16 KB copy; loads are issued one stage ahead (registers), written
+  //      to the other LDS buffer after the current stage's math, one barrier per stage.
+  // (macros over named scalars, not lambdas/arrays: hipcc leaves such an array in scratch memory once
+  //  register pressure rises)
+  double2 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7;
+  uint32_t cnext[NB];
+#define STAGE_LOAD(RB)                                                          \
+  {                                                                             \
+    const double2* srcT_ = (const double2*)(a.LT + (size_t)(RB) * BLK) + threadIdx.x; \
+    const double2* srcG_ = (const double2*)(a.LG + (size_t)(RB) * BLK) + threadIdx.x; \
+    sr0 = srcT_[0];                                                             \
+    sr1 = srcT_[256];                                                           \
+    sr2 = srcT_[512];                                                           \
+    sr3 = srcT_[768];                                                           \
+    sr4 = srcG_[0];                                                             \
+    sr5 = srcG_[256];                                                           \
+    sr6 = srcG_[512];                                                           \
+    sr7 = srcG_[768];                                                           \
+    if (DATA == DATA_BIN) {                                                     \
+      _Pragma("unroll") for (int b_ = 0; b_ < NB; ++b_) cnext[b_] = codes[(size_t)((RB) + b_) * 64]; \
+    }                                                                           \
+  }
+#define STAGE_STORE(BUF)                                                        \
+  {                                                                             \
+    double2* dst_ = (double2*)(lds + (BUF) * STAGE_D) + threadIdx.x;            \
+    dst_[0] = sr0;                                                              \
+    dst_[256] = sr1;                                                            \
+    dst_[512] = sr2;                                                            \
+    dst_[768] = sr3;                                                            \
+    dst_[N2] = sr4;                                                             \
+    dst_[N2 + 256] = sr5;                                                       \
+    dst_[N2 + 512] = sr6;                                                       \
+    dst_[N2 + 768] = sr7;                                                       \
+  }
+
+  uint32_t ccur[NB];
+  STAGE_LOAD(rb0);
+  STAGE_STORE(0);
 #pragma unroll
-      for (int u = 0; u < N2 / 256; ++u) {
-        dst[u * 256 + threadIdx.x] = srcT[u * 256 + threadIdx.x];
-        dst[N2 + u * 256 + threadIdx.x] = srcG[u * 256 + threadIdx.x];
-      }
-    }
-    __syncthreads();
+  for (int b = 0; b < NB; ++b) ccur[b] = cnext[b];
+  __syncthreads();
+
+  int buf = 0;
+  for (int rb = rb0; rb < rb1; rb += NB) {
+    // issue next stage's global loads now; they land while this stage computes (clamped: the last
+    // stage re-reads an in-range block, harmlessly)
+    STAGE_LOAD(min(rb + NB, a.Rb - NB));
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads here: hipcc otherwise sinks each one next to its ds_write
+    const double* base = lds + buf * STAGE_D;
+
+    double lt[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) lt[s] = base[s * 64 + lane];
 
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const double* ldsT = lds + b * BLK;
-      const double* ldsG = lds + NB * BLK + b * BLK;
+      const double* ldsG = base + NB * BLK + b * BLK;
+      // back-product operands of this tile: issued before the Theta chain, consumed after it
+      double lg[4 * KB][4];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lg[kb][r] = ldsG[(kb * 4 + r) * 64 + lane];
+      __builtin_amdgcn_sched_barrier(0);   // LDS reads stay ahead of the Theta chain that hides their latency
 
       // ---- Theta tile: rows 16(rb+b)+4r+q, column 16cb+c in register r of lane (q,c)
       d4 th = {0, 0, 0, 0};
 #pragma unroll
-      for (int s = 0; s < S; ++s) th = __builtin_amdgcn_mfma_f64_16x16x4f64(ldsT[s * 64 + lane], rf[s], th, 0, 0, 0);
+      for (int s = 0; s < S; ++s) th = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[s], rf[s], th, 0, 0, 0);
+
+      // Theta operands of the next tile of this stage
+      if (b + 1 < NB) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) lt[s] = base[(b + 1) * BLK + s * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+      }
 
       // ---- ratios
       double R1[4], R2[4];
       if (DATA == DATA_BIN) {
-        const uint32_t code = codes[(size_t)(rb + b) * 64];
+        const uint32_t code = ccur[b];
+        double dd[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const uint32_t cbits = code >> (8 * r);
@@ -198,11 +253,13 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
           const double t = th[r];
           const double d = ym ? (t + eps) : ((1.0 - t) + eps);
           const double rr = rcp_nr(d);
+          dd[r] = d;
           if (MODE == MODE_H) {
-            const bool valid = cbits & CB_VALID;
+            // Every entry that is not an observed one acts as an observed zero here;
+            // pad entries have Theta == 0 exactly and their operand rows/columns are zero, so they only
+            // touch the loss product, by the constant (1+eps) that reduce_h_kernel divides out.
             R1[r] = ym ? rr : 0.0;
-            R2[r] = (valid && !ym) ? rr : 0.0;
-            prod *= valid ? d : 1.0;
+            R2[r] = ym ? 0.0 : rr;
           } else {
             const bool zo = cbits & CB_ZOBS;
             R1[r] = ym ? rr : (zo ? -rr : 0.0);   // S1 - S2
@@ -210,6 +267,7 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
           }
         }
         if (MODE == MODE_H) {
+          prod *= (dd[0] * dd[1]) * (dd[2] * dd[3]);   // >= 1e-32 per tile: no underflow before frexp
           int e;
           prod = frexp(prod, &e);
           pexp += e;
@@ -246,12 +304,19 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-          const double g = ldsG[(kb * 4 + r) * 64 + lane];
-          acc1[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(g, R1[r], acc1[kb], 0, 0, 0);
-          if (MODE == MODE_H) acc2[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(g, R2[r], acc2[kb], 0, 0, 0);
+          acc1[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(lg[kb][r], R1[r], acc1[kb], 0, 0, 0);
+          if (MODE == MODE_H) acc2[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(lg[kb][r], R2[r], acc2[kb], 0, 0, 0);
         }
       }
     }
+
+    // write the prefetched stage into the other buffer; its last readers finished before the previous
+    // barrier, and this stage's readers use `buf`
+    STAGE_STORE(buf ^ 1);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) ccur[b] = cnext[b];
+    __syncthreads();
+    buf ^= 1;
   }
 
   // ---- epilogue: slabs [chunk][k][column]
@@ -275,6 +340,8 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
       }
     }
   }
+#undef STAGE_LOAD
+#undef STAGE_STORE
   if (MODE == MODE_H) {
     double ll;
     if (DATA == DATA_BIN)
@@ -292,7 +359,7 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
 // ------------------------------------------------------------------------------------------
 __global__ void reduce_h_kernel(const double* __restrict__ slab1, const double* __restrict__ slab2,
                                 const double* __restrict__ lossbuf, double* __restrict__ Pbuf, int chunks,
-                                long long per /* K_pad * nA */, int n_loss, const int* done) {
+                                long long per /* K_pad * nA */, int n_loss, double ll_pad, const int* done) {
   if (*done) return;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < per) {
@@ -308,7 +375,7 @@ __global__ void reduce_h_kernel(const double* __restrict__ slab1, const double* 
     double s = 0;
     for (int j = threadIdx.x; j < n_loss; j += 64) s += lossbuf[j];
     s = wave_sum(s);
-    if (threadIdx.x == 0) Pbuf[2 * per] = s;
+    if (threadIdx.x == 0) Pbuf[2 * per] = s - ll_pad;   // binary path: pad entries each contributed log(1+eps)
   }
 }
 
@@ -734,7 +801,7 @@ constexpr int kNcclSum = 0;       // ncclSum
 template <int KB, int DATA, int MODE>
 hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
   dim3 grid(a.Cb / WG_WAVES, chunks);
-  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE>), grid, dim3(256), STAGE_BYTES, st, a);
+  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE>), grid, dim3(256), 2 * STAGE_BYTES, st, a);
   return hipGetLastError();
 }
 
@@ -829,8 +896,13 @@ int enqueue_h_pass(nbmf_ctx* c) {
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
   }
   const long long per = (long long)c->KP * c->nA;
+  // Binary path: the H-pass multiplies every entry of the padded mA x nA grid into the likelihood
+  // product; a pad entry has Theta == 0 and is not an observed one, so it contributes exactly
+  // fl(fl(1-0)+eps) = 1+eps.  Their total is removed here (before any all-reduce).
+  const double n_pad = (double)c->mA * (double)c->nA - (double)c->m * (double)c->n;
+  const double ll_pad = (c->data_kind == DATA_BIN) ? n_pad * log(1.0 + c->eps) : 0.0;
   hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, a.out1, a.out2,
-                     c->lossbuf, c->Pbuf, c->chunksH, per, c->chunksH * a.Cb, c->flags);
+                     c->lossbuf, c->Pbuf, c->chunksH, per, c->chunksH * a.Cb, ll_pad, c->flags);
   HIPCHK(hipGetLastError());
   if (c->comm) {
     NCCLCHK(g_rccl.AllReduce(c->Pbuf, c->Pbuf, (size_t)(2 * per + 1), kNcclFloat64, kNcclSum, c->comm, c->stream));

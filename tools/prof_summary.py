@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/prof_*/{stats,pmc_*}) into the text summary that is
+committed under profiles/.  Usage: tools/prof_summary.py gpurun_out/prof_r1 > profiles/r1_xxx.txt"""
+import collections
+import csv
+import glob
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"pass_kernel<(\d+), (\d+), (\d+)>", name)
+    if m:
+        kb, data, mode = map(int, m.groups())
+        return f"pass_kernel<K={16*kb},{['BIN','F64','F64M'][data]},{'H' if mode == 0 else 'W'}>"
+    m = re.search(r"(\w+_kernel|__amd_rocclr_\w+)", name)
+    return m.group(1) if m else name[:40]
+
+
+def main(root):
+    print(f"# rocprofv3 summary of {root}")
+    for f in glob.glob(f"{root}/stats/*/*_kernel_stats.csv"):
+        print("\n## --kernel-trace --stats (per kernel)\n")
+        print("%-40s %6s %14s %12s %7s %12s %12s" % ("kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"))
+        for r in csv.DictReader(open(f)):
+            print("%-40s %6s %14s %12.0f %7s %12s %12s" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"],
+                                                          float(r["AverageNs"]), r["Percentage"][:6], r["MinNs"], r["MaxNs"]))
+    for d in sorted(glob.glob(f"{root}/pmc_*")):
+        for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
+            agg = collections.defaultdict(lambda: collections.defaultdict(list))
+            dur = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            print(f"\n## --pmc pass {d.split('/')[-1]} (mean per dispatch)\n")
+            for k in sorted(agg):
+                if not k.startswith("pass_kernel") and "update" not in k and "reduce" not in k:
+                    continue
+                parts = ["%s=%.6g" % (c, sum(v) / len(v)) for c, v in sorted(agg[k].items())]
+                print("%-40s n=%-3d dur_ns=%-10.0f %s" % (k, len(dur[k]) // max(1, len(agg[k])), sum(dur[k]) / len(dur[k]), " ".join(parts)))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1].rstrip("/"))
