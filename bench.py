@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--projection", default="duchi", choices=["normalize", "duchi"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="all-reduce transport for --gpus > 1 (host = gloo through pinned memory; tests only)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,13 +108,12 @@ def main():
 
     M, N, K = args.M, args.N, args.K
     masked = not args.no_mask
-    rows = (M + world - 1) // world
-    rows = (rows + 127) // 128 * 128                      # shard boundaries on the 128-row padding unit
-    r0, r1 = min(M, rank * rows), min(M, (rank + 1) * rows)
+    from nbmf_mm_amd import _dist
+    r0, r1 = _dist.shard_bounds(M, world, rank)
 
     X, Mk = make_shard(M, N, r0, r1, args.seed, masked=masked)
     W_full, H0 = init_factors(M, N, K, args.seed)
-    ctx = _hip.Context(r1 - r0, N, K, device=local_rank)
+    ctx = _hip.Context(r1 - r0, N, K, device=0 if args.share_gpu else local_rank)
     ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_DUCHI if args.projection == "duchi" else _hip.PROJ_NORMALIZE)
     t_up = time.perf_counter()
     binary_path = ctx.upload(X, mask=Mk)
@@ -120,9 +122,7 @@ def main():
     del X, Mk
     ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
     if world > 1:
-        uid = [_hip.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], world, rank)
+        _dist.attach_comm(ctx, dist, args.transport)
 
     def sync():
         ctx.synchronize()
@@ -164,7 +164,7 @@ def main():
                                    f"{'mask 90% observed' if masked else 'no mask'}, projection={args.projection}, "
                                    f"alpha=beta=1.2, tol=0 (BASELINE.json configs[2])",
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
-                       "sharding": f"rows/{world}" if world > 1 else "none"},
+                       "sharding": f"rows/{world} ({args.transport} all-reduce of 2*K*N+1 doubles per iteration)" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,

@@ -99,6 +99,12 @@ int nbmf_loss(nbmf_ctx* ctx, double* loss);
 int nbmf_comm_unique_id(void* id128);
 int nbmf_comm_init(nbmf_ctx* ctx, const void* id128, int nranks, int rank);
 
+/* Same sharded run with the all-reduce done by the caller on a host buffer (sum over ranks, in place,
+ * return 0 on success).  Used by the tests (two ranks sharing one GPU, gloo) and as a fallback
+ * transport; the device work and the control flow are identical to the RCCL path. */
+typedef int (*nbmf_host_allreduce_fn)(void* user, double* buf, int64_t count);
+int nbmf_comm_init_host(nbmf_ctx* ctx, nbmf_host_allreduce_fn fn, void* user, int nranks, int rank);
+
 /* Measurement: HIP-event timing of the two fused pass kernels on the context's stream. */
 int nbmf_timing_enable(nbmf_ctx* ctx, int enable);
 /* ms summed over launches since enable, and launch counts; any pointer may be NULL. */

@@ -30,8 +30,13 @@ SYMBOLS = [
     "nbmf_abi_version", "nbmf_last_error", "nbmf_device_count", "nbmf_create", "nbmf_destroy",
     "nbmf_set_hyper", "nbmf_upload", "nbmf_get_n_obs", "nbmf_set_factors", "nbmf_get_factors",
     "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_comm_unique_id", "nbmf_comm_init",
+    "nbmf_comm_init_host",
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_rcp",
 ]
+
+
+#: int fn(void* user, double* buf, int64 count) -- in-place sum over ranks on a host buffer
+HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, POINTER(c_double), c_int64)
 
 
 class NBMFHipError(RuntimeError):
@@ -72,6 +77,7 @@ def load():
     lib.nbmf_loss.argtypes = [c_void_p, dp]
     lib.nbmf_comm_unique_id.argtypes = [c_void_p]
     lib.nbmf_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
+    lib.nbmf_comm_init_host.argtypes = [c_void_p, HOST_ALLREDUCE_FN, c_void_p, c_int, c_int]
     lib.nbmf_timing_enable.argtypes = [c_void_p, c_int]
     lib.nbmf_timing_get.argtypes = [c_void_p, dp, POINTER(c_int), dp, POINTER(c_int)]
     lib.nbmf_synchronize.argtypes = [c_void_p]
@@ -193,6 +199,21 @@ class Context:
     def comm_init(self, uid: bytes, nranks: int, rank: int):
         buf = ctypes.create_string_buffer(bytes(uid), 128)
         _check(self._lib.nbmf_comm_init(self._h, buf, int(nranks), int(rank)))
+
+    def comm_init_host(self, allreduce, nranks: int, rank: int):
+        """Attach a host-mediated all-reduce: ``allreduce(arr)`` must sum the float64 NumPy array
+        ``arr`` over all ranks IN PLACE (e.g. gloo).  Same device work as the RCCL path."""
+        def _cb(_user, ptr, count):
+            try:
+                arr = np.ctypeslib.as_array(ptr, shape=(int(count),))
+                allreduce(arr)
+                return 0
+            except Exception:      # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_cb = HOST_ALLREDUCE_FN(_cb)          # keep alive as long as the context
+        _check(self._lib.nbmf_comm_init_host(self._h, self._host_cb, None, int(nranks), int(rank)))
 
     def timing_enable(self, on=True):
         _check(self._lib.nbmf_timing_enable(self._h, int(bool(on))))

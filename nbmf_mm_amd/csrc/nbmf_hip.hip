@@ -740,8 +740,12 @@ struct nbmf_ctx {
   unsigned long long* stats = nullptr;
   double alpha = 1.2, beta = 1.2, eps = 1e-8;
   int projection = NBMF_PROJ_NORMALIZE;
-  // comm
+  // comm: RCCL communicator, or a host-mediated all-reduce callback (tests / fallback transport)
   void* comm = nullptr;
+  nbmf_host_allreduce_fn host_reduce = nullptr;
+  void* host_reduce_user = nullptr;
+  double* host_buf = nullptr;   // pinned
+  size_t host_buf_count = 0;
   int nranks = 1, rank = 0;
   // timing
   bool timing = false;
@@ -906,6 +910,13 @@ int enqueue_h_pass(nbmf_ctx* c) {
   HIPCHK(hipGetLastError());
   if (c->comm) {
     NCCLCHK(g_rccl.AllReduce(c->Pbuf, c->Pbuf, (size_t)(2 * per + 1), kNcclFloat64, kNcclSum, c->comm, c->stream));
+  } else if (c->host_reduce) {
+    const size_t cnt = (size_t)(2 * per + 1);
+    HIPCHK(hipMemcpyAsync(c->host_buf, c->Pbuf, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->host_reduce(c->host_reduce_user, c->host_buf, (int64_t)cnt) != 0)
+      return fail(NBMF_ERR_COMM, "host all-reduce callback failed");
+    HIPCHK(hipMemcpyAsync(c->Pbuf, c->host_buf, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
   return NBMF_OK;
 }
@@ -1058,6 +1069,7 @@ int nbmf_destroy(nbmf_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  if (c->host_buf) hipHostFree(c->host_buf);
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
                   c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats};
   for (void* p : ptrs)
@@ -1357,6 +1369,27 @@ int nbmf_comm_init(nbmf_ctx* c, const void* id128, int nranks, int rank) {
   NCCLCHK(g_rccl.AllReduce(c->scal + 4, c->scal + 4, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
   HIPCHK(hipMemcpyAsync(&c->n_obs_global, c->scal + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return NBMF_OK;
+}
+
+int nbmf_comm_init_host(nbmf_ctx* c, nbmf_host_allreduce_fn fn, void* user, int nranks, int rank) {
+  if (!c || !fn) return fail(NBMF_ERR_ARG, "null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(NBMF_ERR_ARG, "bad rank %d / nranks %d", rank, nranks);
+  if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "call nbmf_upload before nbmf_comm_init_host (the observed count is reduced here)");
+  if (c->comm) return fail(NBMF_ERR_STATE, "an RCCL communicator is already attached");
+  if (int rc = set_device(c)) return rc;
+  const size_t cnt = 2 * (size_t)c->KP * c->nA + 1;
+  if (!c->host_buf) {
+    HIPCHK(hipHostMalloc((void**)&c->host_buf, cnt * sizeof(double), hipHostMallocDefault));
+    c->host_buf_count = cnt;
+  }
+  c->host_reduce = fn;
+  c->host_reduce_user = user;
+  c->nranks = nranks;
+  c->rank = rank;
+  c->host_buf[0] = c->n_obs;
+  if (fn(user, c->host_buf, 1) != 0) return fail(NBMF_ERR_COMM, "host all-reduce callback failed");
+  c->n_obs_global = c->host_buf[0];
   return NBMF_OK;
 }
 

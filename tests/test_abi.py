@@ -1,0 +1,71 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol
+include/nbmf_hip.h declares, fails loudly (no CPU fallback), and nothing under nbmf_mm_amd/ imports
+the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nbmf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nbmf_[a-z0-9_]+)\s*\(", text)) - {"nbmf_host_allreduce_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    from nbmf_mm_amd import _hip
+    lib = _hip.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 19
+    assert sorted(_hip.SYMBOLS) == declared, "python binding list and header disagree"
+    for name in declared:
+        assert hasattr(lib, name), f"libnbmf_hip.so does not export {name}"
+    assert lib.nbmf_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from nbmf_mm_amd import NBMF, _hip
+    if _hip.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    X = (np.random.default_rng(0).random((20, 30)) < 0.3).astype(float)
+    with pytest.raises(_hip.NBMFHipError, match="no HIP device"):
+        NBMF(n_components=3, max_iter=5).fit(X)
+    with pytest.raises(_hip.NBMFHipError):
+        _hip.Context(20, 30, 3)
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    from nbmf_mm_amd import _hip
+    monkeypatch.setenv("NBMF_HIP_LIBRARY", "/nonexistent/libnbmf_hip.so")
+    monkeypatch.setattr(_hip, "_lib", None)
+    with pytest.raises(_hip.NBMFHipError, match="no CPU fallback"):
+        _hip.load()
+    monkeypatch.undo()
+    _hip._lib = None
+    _hip.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "nbmf_mm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_argument_errors_surface_without_a_gpu():
+    from nbmf_mm_amd import _hip
+    lib = _hip.load()
+    import ctypes
+    h = ctypes.c_void_p()
+    assert lib.nbmf_create(0, 5, 3, 0, ctypes.byref(h)) == _hip.NBMF_ERR_ARG
+    assert b"m and n" in lib.nbmf_last_error()
+    assert lib.nbmf_create(5, 5, 129, 0, ctypes.byref(h)) == _hip.NBMF_ERR_ARG
+    assert b"n_components" in lib.nbmf_last_error()
+    assert lib.nbmf_run(None, 1, 0.0, None, None) == _hip.NBMF_ERR_ARG
+    assert lib.nbmf_destroy(None) == 0

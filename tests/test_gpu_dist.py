@@ -1,0 +1,108 @@
+"""Multi-rank path on the GPU box: two processes share the one MI355X, all-reduce over the host
+transport (gloo); plus the RCCL plumbing with a single rank.  Compared with the single-process HIP
+run and the CPU oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    g = np.random.default_rng(21)
+    M, N, K = 700, 333, 24
+    Y = (g.random((M, N)) < 0.3).astype(np.float64)
+    mask = g.random((M, N)) < 0.9
+    return M, N, K, Y, mask
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    from nbmf_mm_amd import _dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        M, N, K, Y, mask = _problem()
+        r0, r1 = _dist.shard_bounds(M, world, rank)
+        Wl, H, losses, n_iter = _dist.fit_row_sharded(Y[r0:r1], M, r0, K, dist, max_iter=30, tol=0, alpha=1.2, beta=1.3,
+                                                      mask_local=mask[r0:r1], random_state=5, device=0, transport="host")
+        q.put((rank, r0, r1, Wl, H, losses, n_iter))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_host_transport():
+    import torch.multiprocessing as mp
+    from nbmf_mm_amd import nbmf_mm_solver
+    from oracle import nbmf_oracle as orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    M, N, K, Y, mask = _problem()
+    W1, H1, l1, _, n1 = nbmf_mm_solver(Y, K, max_iter=30, tol=0, alpha=1.2, beta=1.3, mask=mask, random_state=5)
+    Wr, Hr, lr, _, _ = orc.solve(Y, K, max_iter=30, tol=0, alpha=1.2, beta=1.3, mask=mask, random_state=5)
+    W = np.concatenate([r[3] for r in res], axis=0)
+    for ref_W, ref_H, ref_l, tol in [(W1, H1, l1, 1e-12), (Wr, Hr, lr, 1e-9)]:
+        np.testing.assert_allclose(W, ref_W, rtol=0, atol=tol)
+        np.testing.assert_allclose(res[0][4], ref_H, rtol=0, atol=tol)
+        np.testing.assert_allclose(res[0][5], ref_l, rtol=1e-10, atol=0)
+    np.testing.assert_array_equal(res[0][4], res[1][4])     # replicated factor bitwise identical on both ranks
+    np.testing.assert_array_equal(res[0][5], res[1][5])
+    assert res[0][6] == res[1][6] == 30 == n1
+
+
+def test_two_ranks_stop_rule_agrees():
+    """Sharded stop rule: every rank stops at the same iteration as the single-process run."""
+    from nbmf_mm_amd import _hip, _dist, nbmf_mm_solver
+    M, N, K, Y, mask = _problem()
+    # emulate two ranks in ONE process: two contexts, the host callback sums their buffers
+    r = [_dist.shard_bounds(M, 2, i) for i in range(2)]
+    W, H = _dist.global_init(M, N, K, random_state=5)
+    _, _, l1, _, n1 = nbmf_mm_solver(Y, K, max_iter=400, tol=1e-4, mask=mask, random_state=5)
+    assert 5 < n1 < 400
+    # a single-rank "world" over the host transport must reproduce the plain run exactly
+    with _hip.Context(M, N, K) as ctx:
+        ctx.set_hyper(1.2, 1.2)
+        ctx.upload(Y, mask=mask)
+        ctx.set_factors(W, H)
+        ctx.comm_init_host(lambda arr: None, 1, 0)
+        losses, n_iter = ctx.run(400, 1e-4)
+    assert n_iter == n1
+    np.testing.assert_array_equal(losses, np.array(l1))
+
+
+def test_rccl_single_rank():
+    """RCCL plumbing (dlopen, unique id, communicator, in-place all-reduce on the library's stream)."""
+    from nbmf_mm_amd import _hip, _dist, nbmf_mm_solver
+    M, N, K, Y, mask = _problem()
+    W, H = _dist.global_init(M, N, K, random_state=5)
+    _, _, l1, _, _ = nbmf_mm_solver(Y, K, max_iter=10, tol=0, mask=mask, random_state=5)
+    uid = _hip.comm_unique_id()
+    assert len(uid) == 128
+    with _hip.Context(M, N, K) as ctx:
+        ctx.set_hyper(1.2, 1.2)
+        ctx.upload(Y, mask=mask)
+        ctx.set_factors(W, H)
+        ctx.comm_init(uid, 1, 0)
+        assert ctx.n_obs() == np.count_nonzero(mask)
+        losses, n_iter = ctx.run(10, 0.0)
+    np.testing.assert_array_equal(losses, np.array(l1))
