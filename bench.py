@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="all-reduce transport for --gpus > 1 (host = gloo through pinned memory; tests only)")
+    ap.add_argument("--no-events", action="store_true", help="do not record HIP events around the pass kernels (overhead check)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -132,7 +133,7 @@ def main():
 
     if args.warmup > 0:
         ctx.run(args.warmup, 0.0)
-    ctx.timing_enable(True)
+    ctx.timing_enable(not args.no_events)
     sync()
     t0 = time.perf_counter()
     losses, n_iter = ctx.run(args.steps, 0.0)

@@ -111,9 +111,9 @@ int nbmf_timing_enable(nbmf_ctx* ctx, int enable);
 int nbmf_timing_get(nbmf_ctx* ctx, double* hpass_ms, int* hpass_launches, double* wpass_ms, int* wpass_launches);
 int nbmf_synchronize(nbmf_ctx* ctx);
 
-/* Self-test hook used by the GPU tests: max relative error of the kernel's Newton reciprocal
- * against IEEE division over n samples of the denominator range [eps, 1+eps]. */
-int nbmf_selftest_rcp(int device, int n, double* max_rel_err);
+/* Self-test hook used by the GPU tests: runs the pass kernel's Newton reciprocal on n caller-supplied
+ * denominators and returns the results (compared on the host with IEEE 1/d). */
+int nbmf_selftest_rcp(int device, int n, const double* denominators, double* reciprocals);
 
 #ifdef __cplusplus
 }

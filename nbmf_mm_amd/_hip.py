@@ -81,7 +81,7 @@ def load():
     lib.nbmf_timing_enable.argtypes = [c_void_p, c_int]
     lib.nbmf_timing_get.argtypes = [c_void_p, dp, POINTER(c_int), dp, POINTER(c_int)]
     lib.nbmf_synchronize.argtypes = [c_void_p]
-    lib.nbmf_selftest_rcp.argtypes = [c_int, c_int, dp]
+    lib.nbmf_selftest_rcp.argtypes = [c_int, c_int, c_void_p, c_void_p]
     for name in SYMBOLS:
         if name != "nbmf_last_error":
             getattr(lib, name).restype = c_int
@@ -233,7 +233,9 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
-def selftest_rcp(n=1 << 20, device=0) -> float:
-    v = c_double(0)
-    _check(load().nbmf_selftest_rcp(int(device), int(n), byref(v)))
-    return v.value
+def selftest_rcp(denominators, device=0):
+    """Reciprocals of `denominators` computed by the pass kernel's Newton step (GPU tests)."""
+    d = _f64c(denominators).ravel()
+    out = np.empty_like(d)
+    _check(load().nbmf_selftest_rcp(int(device), int(d.size), d.ctypes.data_as(c_void_p), out.ctypes.data_as(c_void_p)))
+    return out

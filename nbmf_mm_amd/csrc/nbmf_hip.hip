@@ -80,12 +80,17 @@ constexpr int STAGE_BYTES = 32768; // one LDS stage: NB row blocks x (T + G oper
 // this range).  Stands in for the IEEE divides of _solver.py:42-43,53 on the binary path, where the
 // numerator is exactly 0 or 1.
 __device__ __forceinline__ double rcp_nr(double d) {
+  // seed, then one cubically convergent step: r1 = r0 (1 + e + e^2), e = 1 - d r0  (3 FMAs;
+  // |e| <= 2^-20 for v_rcp_f64, so the truncation term e^3 is far below 1 ulp)
   double r = __builtin_amdgcn_rcp(d);
-  double e = __builtin_fma(-d, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-d, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  return r;
+  const double e = __builtin_fma(-d, r, 1.0);
+  const double p = __builtin_fma(e, e, e);
+  return __builtin_fma(r, p, r);
+}
+
+// double from its two 32-bit halves / back (bit-level selects cost one VALU op per half)
+__device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) {
+  return __hiloint2double((int)hi, (int)lo);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -248,22 +253,28 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
         double dd[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const uint32_t cbits = code >> (8 * r);
-          const bool ym = cbits & CB_YM;
-          const double t = th[r];
-          const double d = ym ? (t + eps) : ((1.0 - t) + eps);
+          // m = all-ones where this entry is an observed one (ym), else 0
+          const uint32_t m = (uint32_t)(-(int)((code >> (8 * r)) & 1u));
+          // d = ym ? Theta+eps : (1-Theta)+eps as fma(s, Theta, z) + eps with (s, z) = (1, 0) or (-1, 1):
+          // one rounding for 1-Theta, exact for Theta, so bit-identical to the reference expressions
+          // (including Theta > 1, which the un-normalised start of transform() can produce)
+          const double z = mk_double(0u, ~m & 0x3FF00000u);
+          const double sg = mk_double(0u, (~m & 0x80000000u) | 0x3FF00000u);
+          const double d = __builtin_fma(sg, th[r], z) + eps;
           const double rr = rcp_nr(d);
           dd[r] = d;
+          const uint32_t rlo = (uint32_t)__double2loint(rr), rhi = (uint32_t)__double2hiint(rr);
           if (MODE == MODE_H) {
             // Every entry that is not an observed one acts as an observed zero here;
             // pad entries have Theta == 0 exactly and their operand rows/columns are zero, so they only
-            // touch the loss product, by the constant (1+eps) that reduce_h_kernel divides out.
-            R1[r] = ym ? rr : 0.0;
-            R2[r] = ym ? 0.0 : rr;
+            // touch the loss product, by the constant (1+eps) that is divided out before the loss.
+            R1[r] = mk_double(rlo & m, rhi & m);        // ym ? rr : 0
+            R2[r] = mk_double(rlo & ~m, rhi & ~m);      // ym ? 0 : rr
           } else {
-            const bool zo = cbits & CB_ZOBS;
-            R1[r] = ym ? rr : (zo ? -rr : 0.0);   // S1 - S2
-            s2 += zo ? rr : 0.0;
+            const uint32_t zo = (uint32_t)(-(int)((code >> (8 * r + 1)) & 1u));   // observed zero
+            const uint32_t keep = m | zo;
+            R1[r] = mk_double(rlo & keep, (rhi ^ (zo & 0x80000000u)) & keep);     // S1 - S2: +rr, -rr or 0
+            s2 += mk_double(rlo & zo, rhi & zo);
           }
         }
         if (MODE == MODE_H) {
@@ -354,12 +365,27 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
 }
 
 // ------------------------------------------------------------------------------------------
-// Ordered reduction of the H-pass slabs: Pbuf[t][k][j] = sum_chunks slab[t][chunk][k][j], and the
-// log-likelihood partials -> Pbuf tail.  (In multi-GPU runs Pbuf is what RCCL all-reduces.)
+// Deterministic block-wide sum (256 threads): thread t adds p[t*stride], p[(t+256)*stride], ... in
+// order, then a fixed butterfly inside each wave and the four waves in order.  Every thread must call
+// it; the result is returned to thread 0 (other threads get garbage).
 // ------------------------------------------------------------------------------------------
-__global__ void reduce_h_kernel(const double* __restrict__ slab1, const double* __restrict__ slab2,
-                                const double* __restrict__ lossbuf, double* __restrict__ Pbuf, int chunks,
-                                long long per /* K_pad * nA */, int n_loss, double ll_pad, const int* done) {
+__device__ __forceinline__ double ordered_sum256(const double* __restrict__ p, int n, int stride, double* sh4) {
+  double s = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) s += p[(size_t)j * stride];
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return ((sh4[0] + sh4[1]) + sh4[2]) + sh4[3];
+}
+
+// Multi-GPU only: ordered reduction of the H-pass slabs into the all-reduce payload
+// Pbuf = [P1 | P2 | loglik]: Pbuf[t][k][j] = sum_chunks slab[t][chunk][k][j].
+__global__ __launch_bounds__(256) void reduce_h_kernel(const double* __restrict__ slab1, const double* __restrict__ slab2,
+                                                       const double* __restrict__ lossbuf, double* __restrict__ Pbuf,
+                                                       int chunks, long long per /* K_pad * nA */, int n_loss,
+                                                       double ll_pad, const int* done) {
+  __shared__ double sh4[4];
   if (*done) return;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < per) {
@@ -371,10 +397,8 @@ __global__ void reduce_h_kernel(const double* __restrict__ slab1, const double* 
     Pbuf[i] = s1;
     Pbuf[per + i] = s2;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
-    double s = 0;
-    for (int j = threadIdx.x; j < n_loss; j += 64) s += lossbuf[j];
-    s = wave_sum(s);
+  if (blockIdx.x == 0) {
+    const double s = ordered_sum256(lossbuf, n_loss, 1, sh4);
     if (threadIdx.x == 0) Pbuf[2 * per] = s - ll_pad;   // binary path: pad entries each contributed log(1+eps)
   }
 }
@@ -401,27 +425,34 @@ __device__ __forceinline__ void block_sum2(double a, double b, double* out2) {
   }
 }
 
-// H-update (_solver.py:42-47) from the reduced products; writes natural, T and G forms.
-// One thread per (k, j); j fastest.
-__global__ __launch_bounds__(256) void h_update_kernel(const double* __restrict__ Pbuf, double* __restrict__ Hn,
-                                                       double* __restrict__ HT, double* __restrict__ HG,
-                                                       double* __restrict__ prior, int K, int KP, long long n,
-                                                       long long nA, double am1, double bm1, double eps,
+// H-update (_solver.py:42-47); P1/P2 are summed here over `chunks` partial slabs in chunk order
+// (single GPU: the H-pass slabs; multi-GPU: the all-reduced Pbuf, chunks = 1).  Writes natural, T and
+// G forms.  One thread per (k, j); j fastest.
+__global__ __launch_bounds__(256) void h_update_kernel(const double* __restrict__ src1, const double* __restrict__ src2,
+                                                       int chunks, double* __restrict__ Hn, double* __restrict__ HT,
+                                                       double* __restrict__ HG, double* __restrict__ prior, int K, int KP,
+                                                       long long n, long long nA, double am1, double bm1, double eps,
                                                        const int* done) {
   if (*done) return;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long k = idx / nA, j = idx % nA;
+  const size_t per = (size_t)KP * nA;
   double la = 0, lb = 0;
   if (k < KP) {
     double h = 0.0;
     if (k < K && j < n) {
+      double p1 = 0, p2 = 0;
+      for (int ch = 0; ch < chunks; ++ch) {
+        p1 += src1[(size_t)ch * per + idx];
+        p2 += src2[(size_t)ch * per + idx];
+      }
       const double hold = Hn[idx];
-      const double num = hold * Pbuf[idx] + am1;                             // :42
-      const double den = (1.0 - hold) * Pbuf[(size_t)KP * nA + idx] + bm1;   // :43
-      h = num / (num + den + eps);                                           // :46
-      h = fmin(fmax(h, eps), 1.0 - eps);                                     // :47
-      la = log(h + eps);                                                     // :158
-      lb = log(1.0 - h + eps);                                               // :159
+      const double num = hold * p1 + am1;             // :42
+      const double den = (1.0 - hold) * p2 + bm1;     // :43
+      h = num / (num + den + eps);                    // :46
+      h = fmin(fmax(h, eps), 1.0 - eps);              // :47
+      la = log(h + eps);                              // :158
+      lb = log(1.0 - h + eps);                        // :159
     }
     Hn[idx] = h;
     const long long jb = j >> 4, c = j & 15;
@@ -445,21 +476,20 @@ __global__ __launch_bounds__(256) void prior_kernel(const double* __restrict__ H
   block_sum2(la, lb, prior + 2 * (size_t)blockIdx.x);
 }
 
-// Loss assembly + stop rule (_solver.py:158-175), one wave.
+// Loss assembly + stop rule (_solver.py:158-175), one 256-thread block.
+//   ll = ordered sum of ll_src[0..n_ll) - ll_pad   (single GPU: the per-wave H-pass partials;
+//                                                     multi-GPU: the all-reduced Pbuf tail, n_ll = 1)
 //   scal[0] = previous loss, flags[0] = done, flags[1] = n_iter
-__global__ void finalize_kernel(const double* __restrict__ Pbuf, long long ll_index, const double* __restrict__ prior,
-                                int n_prior, double am1, double bm1, double n_obs, double* __restrict__ losses,
-                                int t, double tol, double* __restrict__ scal, int* __restrict__ flags) {
+__global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict__ ll_src, int n_ll, double ll_pad,
+                                                       const double* __restrict__ prior, int n_prior, double am1,
+                                                       double bm1, double n_obs, double* __restrict__ losses, int t,
+                                                       double tol, double* __restrict__ scal, int* __restrict__ flags) {
+  __shared__ double sh4[4];
   if (flags[0]) return;
-  double sa = 0, sb = 0;
-  for (int i = threadIdx.x; i < n_prior; i += 64) {
-    sa += prior[2 * i];
-    sb += prior[2 * i + 1];
-  }
-  sa = wave_sum(sa);
-  sb = wave_sum(sb);
+  const double ll = ordered_sum256(ll_src, n_ll, 1, sh4) - ll_pad;
+  const double sa = ordered_sum256(prior, n_prior, 2, sh4);
+  const double sb = ordered_sum256(prior + 1, n_prior, 2, sh4);
   if (threadIdx.x == 0) {
-    const double ll = Pbuf[ll_index];
     const double A = am1 * sa;
     const double B = bm1 * sb;
     const double loss = -(ll + A + B) / n_obs;   // :162
@@ -473,70 +503,79 @@ __global__ void finalize_kernel(const double* __restrict__ Pbuf, long long ll_in
   }
 }
 
-// W-update (_solver.py:53-57): thread per column i.  Q = sum over chunks of the W-pass slabs.
-// projection 0: (W*Q)/n then divide by the column sum.  projection 1 (extension): (W*Q)/count_i then
-// Euclidean projection onto the simplex (Michelot active-set iteration; unique minimiser).
+// W-update (_solver.py:53-57).  Block = 32 columns x 8 k-groups: every thread reduces the W-pass slabs
+// for its (k, column) entries (coalesced over columns) into an LDS tile of products W*Q/div; one
+// thread per column then sums the K products in k order (the order of numpy's sum(axis=0)) and
+//   projection 0: divides by the column sum (:57);
+//   projection 1 (extension, README.md:27-35): div = per-row observed count, then Euclidean
+//                 projection onto the simplex by Michelot's active-set iteration (unique minimiser);
+// all threads write natural, T and G forms.
+constexpr int WU_COLS = 32, WU_GROUPS = 8;
 __global__ __launch_bounds__(256) void w_update_kernel(const double* __restrict__ slab, int chunks, double* __restrict__ Wn,
                                                        double* __restrict__ WT, double* __restrict__ WG, int K, int KP,
                                                        long long m, long long mA, double n_div,
                                                        const double* __restrict__ rowcnt, int projection,
                                                        const int* done) {
+  extern __shared__ __attribute__((aligned(16))) double tile[];   // [KP][WU_COLS] products, then [2][WU_COLS] scale/tau
   if (*done) return;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= mA) return;
+  const int c = threadIdx.x & (WU_COLS - 1), g = threadIdx.x / WU_COLS;
+  const long long i = (long long)blockIdx.x * WU_COLS + c;
   const size_t per = (size_t)KP * mA;
-  const long long ib = i >> 4, c = i & 15;
-  if (i >= m) {
-    for (int k = 0; k < KP; ++k) {
-      Wn[(size_t)k * mA + i] = 0.0;
-      WT[(ib * KP + k) * 16 + c] = 0.0;
-      WG[ib * KP * 16 + (k >> 4) * 256 + c * 16 + (k & 15)] = 0.0;
-    }
-    return;
-  }
-  const double div = (projection == NBMF_PROJ_DUCHI && rowcnt) ? fmax(rowcnt[i], 1.0) : n_div;
-  double sum = 0.0;
-  for (int k = 0; k < K; ++k) {
-    double qv = 0.0;
-    for (int ch = 0; ch < chunks; ++ch) qv += slab[(size_t)ch * per + (size_t)k * mA + i];
-    const double w = (Wn[(size_t)k * mA + i] * qv) / div;   // :53-54
-    Wn[(size_t)k * mA + i] = w;                              // staged in place (own column only)
-    sum += w;
-  }
-  double tau = 0.0, scale = 1.0;
-  if (projection == NBMF_PROJ_DUCHI) {
-    // Michelot: tau = (sum_{active} v - 1)/|active|, drop v <= tau, repeat until stable.
-    tau = (sum - 1.0) / K;
-    int cnt = K;
-    for (int it = 0; it < K; ++it) {
-      double s = 0.0;
-      int c2 = 0;
-      for (int k = 0; k < K; ++k) {
-        const double v = Wn[(size_t)k * mA + i];
-        if (v > tau) {
-          s += v;
-          ++c2;
-        }
-      }
-      if (c2 == 0) break;
-      const double t2 = (s - 1.0) / c2;
-      const bool same = (c2 == cnt);
-      tau = t2;
-      cnt = c2;
-      if (same) break;
-    }
-  } else {
-    scale = sum;
-  }
-  for (int k = 0; k < KP; ++k) {
+  const bool live = i < m;
+  double div = n_div;
+  if (live && projection == NBMF_PROJ_DUCHI && rowcnt) div = fmax(rowcnt[i], 1.0);
+  for (int k = g; k < K; k += WU_GROUPS) {
     double w = 0.0;
-    if (k < K) {
-      const double v = Wn[(size_t)k * mA + i];
+    if (live) {
+      double qv = 0.0;
+      for (int ch = 0; ch < chunks; ++ch) qv += slab[(size_t)ch * per + (size_t)k * mA + i];
+      w = (Wn[(size_t)k * mA + i] * qv) / div;   // :53-54
+    }
+    tile[k * WU_COLS + c] = w;
+  }
+  __syncthreads();
+  double* par = tile + (size_t)KP * WU_COLS;      // [0][c] = scale, [1][c] = tau
+  if (g == 0) {
+    double sum = 0.0;
+    for (int k = 0; k < K; ++k) sum += tile[k * WU_COLS + c];
+    double tau = 0.0, scale = 1.0;
+    if (projection == NBMF_PROJ_DUCHI) {
+      tau = (sum - 1.0) / K;
+      int cnt = K;
+      for (int it = 0; it < K; ++it) {
+        double s = 0.0;
+        int c2 = 0;
+        for (int k = 0; k < K; ++k) {
+          const double v = tile[k * WU_COLS + c];
+          if (v > tau) {
+            s += v;
+            ++c2;
+          }
+        }
+        if (c2 == 0) break;
+        const bool same = (c2 == cnt);
+        tau = (s - 1.0) / c2;
+        cnt = c2;
+        if (same) break;
+      }
+    } else {
+      scale = sum;
+    }
+    par[c] = scale;
+    par[WU_COLS + c] = tau;
+  }
+  __syncthreads();
+  const double scale = par[c], tau = par[WU_COLS + c];
+  const long long ib = i >> 4, cc = i & 15;
+  for (int k = g; k < KP; k += WU_GROUPS) {
+    double w = 0.0;
+    if (live && k < K) {
+      const double v = tile[k * WU_COLS + c];
       w = (projection == NBMF_PROJ_DUCHI) ? fmax(v - tau, 0.0) : v / scale;   // :57
     }
     Wn[(size_t)k * mA + i] = w;
-    WT[(ib * KP + k) * 16 + c] = w;
-    WG[ib * KP * 16 + (k >> 4) * 256 + c * 16 + (k & 15)] = w;
+    WT[(ib * KP + k) * 16 + cc] = w;
+    WG[ib * KP * 16 + (k >> 4) * 256 + cc * 16 + (k & 15)] = w;
   }
 }
 
@@ -702,15 +741,9 @@ __global__ void rowcount_kernel(const void* dataB, const void* maskB, int data_k
   rowcnt[i] = s;
 }
 
-__global__ void rcp_test_kernel(double* out, int n, double eps) {
+__global__ void rcp_test_kernel(const double* __restrict__ d, double* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  // log-uniform-ish sweep of [eps, 1+eps]
-  const double u = (i + 0.5) / n;
-  const double d = exp(log(eps) * (1.0 - u)) * (1.0 + 1e-3 * (i % 7)) + eps;
-  const double dd = fmin(d, 1.0 + eps);
-  const double ref = 1.0 / dd;
-  out[i] = fabs(rcp_nr(dd) - ref) / ref;
+  if (i < n) out[i] = rcp_nr(d[i]);
 }
 
 }  // namespace
@@ -832,11 +865,15 @@ hipError_t launch_pass(int KB, int data_kind, const PassArgs& a, int chunks, hip
 
 void pick_chunks(int strips_groups, int Rb, int NB, int* chunks, int* CH) {
   // aim for >= ~2048 workgroups (256 CUs x 2 resident x 4 rounds) without making chunks tiny
-  int want = (2048 + strips_groups - 1) / strips_groups;
+  // (NBMF_TARGET_WGS overrides the target: tuning experiments only)
+  int target = 2048;
+  if (const char* e = getenv("NBMF_TARGET_WGS")) target = std::max(1, atoi(e));
+  int want = (target + strips_groups - 1) / strips_groups;
   int max_chunks = Rb / NB;
   if (want > max_chunks) want = max_chunks;
   if (want < 1) want = 1;
   int ch = (Rb + want - 1) / want;
+  ch = std::max(ch, std::min(Rb, 64));   // short sweeps pay the per-workgroup prologue/epilogue and slab traffic
   ch = (int)round_up(ch, NB);
   *CH = ch;
   *chunks = (Rb + ch - 1) / ch;
@@ -879,6 +916,15 @@ void timing_collect(nbmf_ctx* c) {
   c->ev_used = 0;
 }
 
+// Binary path: the H-pass multiplies every entry of the padded mA x nA grid into the likelihood
+// product; a pad entry has Theta == 0 and is not an observed one, so it contributes exactly
+// fl(fl(1-0)+eps) = 1+eps.  Their total is removed before the loss is assembled (and before any
+// all-reduce).
+double ll_pad_of(const nbmf_ctx* c) {
+  const double n_pad = (double)c->mA * (double)c->nA - (double)c->m * (double)c->n;
+  return (c->data_kind == DATA_BIN) ? n_pad * log(1.0 + c->eps) : 0.0;
+}
+
 int enqueue_h_pass(nbmf_ctx* c) {
   PassArgs a{};
   a.data = c->dataA;
@@ -899,40 +945,45 @@ int enqueue_h_pass(nbmf_ctx* c) {
     EvScope ev(c, 0);
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
   }
-  const long long per = (long long)c->KP * c->nA;
-  // Binary path: the H-pass multiplies every entry of the padded mA x nA grid into the likelihood
-  // product; a pad entry has Theta == 0 and is not an observed one, so it contributes exactly
-  // fl(fl(1-0)+eps) = 1+eps.  Their total is removed here (before any all-reduce).
-  const double n_pad = (double)c->mA * (double)c->nA - (double)c->m * (double)c->n;
-  const double ll_pad = (c->data_kind == DATA_BIN) ? n_pad * log(1.0 + c->eps) : 0.0;
-  hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, a.out1, a.out2,
-                     c->lossbuf, c->Pbuf, c->chunksH, per, c->chunksH * a.Cb, ll_pad, c->flags);
-  HIPCHK(hipGetLastError());
-  if (c->comm) {
-    NCCLCHK(g_rccl.AllReduce(c->Pbuf, c->Pbuf, (size_t)(2 * per + 1), kNcclFloat64, kNcclSum, c->comm, c->stream));
-  } else if (c->host_reduce) {
+  if (c->comm || c->host_reduce) {
+    const long long per = (long long)c->KP * c->nA;
+    hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, a.out1, a.out2,
+                       c->lossbuf, c->Pbuf, c->chunksH, per, c->chunksH * a.Cb, ll_pad_of(c), c->flags);
+    HIPCHK(hipGetLastError());
     const size_t cnt = (size_t)(2 * per + 1);
-    HIPCHK(hipMemcpyAsync(c->host_buf, c->Pbuf, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->host_reduce(c->host_reduce_user, c->host_buf, (int64_t)cnt) != 0)
-      return fail(NBMF_ERR_COMM, "host all-reduce callback failed");
-    HIPCHK(hipMemcpyAsync(c->Pbuf, c->host_buf, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (c->comm) {
+      NCCLCHK(g_rccl.AllReduce(c->Pbuf, c->Pbuf, cnt, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    } else {
+      HIPCHK(hipMemcpyAsync(c->host_buf, c->Pbuf, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->host_reduce(c->host_reduce_user, c->host_buf, (int64_t)cnt) != 0)
+        return fail(NBMF_ERR_COMM, "host all-reduce callback failed");
+      HIPCHK(hipMemcpyAsync(c->Pbuf, c->host_buf, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
   }
   return NBMF_OK;
 }
 
 int enqueue_finalize(nbmf_ctx* c, int t, double tol) {
   const long long per = (long long)c->KP * c->nA;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, c->stream, c->Pbuf, 2 * per, c->prior, c->n_prior_blocks,
-                     c->alpha - 1.0, c->beta - 1.0, c->n_obs_global, c->losses_d, t, tol, c->scal, c->flags);
+  const bool sharded = c->comm || c->host_reduce;
+  const double* ll_src = sharded ? c->Pbuf + 2 * per : c->lossbuf;
+  const int n_ll = sharded ? 1 : c->chunksH * (int)(c->nA / 16);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, ll_src, n_ll, sharded ? 0.0 : ll_pad_of(c),
+                     c->prior, c->n_prior_blocks, c->alpha - 1.0, c->beta - 1.0, c->n_obs_global, c->losses_d, t, tol,
+                     c->scal, c->flags);
   HIPCHK(hipGetLastError());
   return NBMF_OK;
 }
 
 int enqueue_h_update(nbmf_ctx* c) {
-  hipLaunchKernelGGL(h_update_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Pbuf, c->Hn, c->HT, c->HG,
-                     c->prior, c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps,
-                     c->flags);
+  const size_t per = (size_t)c->KP * c->nA;
+  const bool sharded = c->comm || c->host_reduce;
+  const double* s1 = sharded ? c->Pbuf : c->slabH;
+  const double* s2 = sharded ? c->Pbuf + per : c->slabH + (size_t)c->chunksH * per;
+  hipLaunchKernelGGL(h_update_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, s1, s2,
+                     sharded ? 1 : c->chunksH, c->Hn, c->HT, c->HG, c->prior, c->k, c->KP, (long long)c->n,
+                     (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags);
   HIPCHK(hipGetLastError());
   return NBMF_OK;
 }
@@ -957,7 +1008,8 @@ int enqueue_w_step(nbmf_ctx* c, int projection) {
     EvScope ev(c, 1);
     HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, a, c->chunksW, c->stream));
   }
-  hipLaunchKernelGGL(w_update_kernel, dim3((unsigned)((c->mA + 255) / 256)), dim3(256), 0, c->stream, c->slabW,
+  hipLaunchKernelGGL(w_update_kernel, dim3((unsigned)(c->mA / WU_COLS)), dim3(WU_COLS * WU_GROUPS),
+                     sizeof(double) * ((size_t)c->KP + 2) * WU_COLS, c->stream, c->slabW,
                      c->chunksW, c->Wn, c->WT, c->WG, c->k, c->KP, (long long)c->m, (long long)c->mA, (double)c->n,
                      c->rowcnt, projection, c->flags);
   HIPCHK(hipGetLastError());
@@ -1418,19 +1470,18 @@ int nbmf_synchronize(nbmf_ctx* c) {
   return NBMF_OK;
 }
 
-int nbmf_selftest_rcp(int device, int n, double* max_rel_err) {
-  if (!max_rel_err || n < 1) return fail(NBMF_ERR_ARG, "bad argument");
+int nbmf_selftest_rcp(int device, int n, const double* denominators, double* reciprocals) {
+  if (!denominators || !reciprocals || n < 1) return fail(NBMF_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(device));
-  double* d = nullptr;
+  double *d = nullptr, *o = nullptr;
   HIPCHK(hipMalloc(&d, sizeof(double) * (size_t)n));
-  hipLaunchKernelGGL(rcp_test_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d, n, 1e-8);
+  HIPCHK(hipMalloc(&o, sizeof(double) * (size_t)n));
+  HIPCHK(hipMemcpy(d, denominators, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(rcp_test_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d, o, n);
   HIPCHK(hipGetLastError());
-  std::vector<double> h((size_t)n);
-  HIPCHK(hipMemcpy(h.data(), d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(reciprocals, o, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
   hipFree(d);
-  double mx = 0;
-  for (double v : h) mx = v > mx ? v : mx;
-  *max_rel_err = mx;
+  hipFree(o);
   return NBMF_OK;
 }
 

@@ -34,8 +34,16 @@ def _one_step(hip, Y, W, H, mask, al, be, projection=0):
 
 
 def test_reciprocal_accuracy(hip):
-    # Newton reciprocal used on the binary path: <= 1 ulp over the denominator range [eps, 1+eps]
-    assert hip.selftest_rcp(1 << 20) <= 2.3e-16
+    # Newton reciprocal used on the binary path: <= 1 ulp of the IEEE quotient over the denominator
+    # range [eps, 1+eps] (log-uniform), plus negative / >1 denominators that transform() can produce
+    r = np.random.default_rng(0)
+    d = np.concatenate([np.exp(r.uniform(np.log(1e-8), 0.0, 1 << 20)) + 1e-8, -r.uniform(1e-8, 3.0, 1 << 16),
+                        r.uniform(1.0, 50.0, 1 << 16), [1e-8, 1.0 + 1e-8, 2e-8]])
+    got = hip.selftest_rcp(d)
+    want = 1.0 / d
+    ulp = np.abs(got - want) / np.spacing(np.abs(want))
+    assert ulp.max() <= 1.0, ulp.max()
+    assert (ulp == 0).mean() > 0.9
 
 
 def test_one_step_golden_vectors(hip, golden):
