@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--projection", default="duchi", choices=["normalize", "duchi"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host"],
                     help="all-reduce transport for --gpus > 1 (host = gloo through pinned memory; tests only)")
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events around the pass kernels (overhead check)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal on a 1-GPU box)")
@@ -122,8 +122,9 @@ def main():
     bytes_up = X.nbytes + (Mk.nbytes if masked else 0)
     del X, Mk
     ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
+    transport = "none"
     if world > 1:
-        _dist.attach_comm(ctx, dist, args.transport)
+        transport = _dist.attach_comm(ctx, dist, args.transport)
 
     def sync():
         ctx.synchronize()
@@ -165,7 +166,7 @@ def main():
                                    f"{'mask 90% observed' if masked else 'no mask'}, projection={args.projection}, "
                                    f"alpha=beta=1.2, tol=0 (BASELINE.json configs[2])",
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
-                       "sharding": f"rows/{world} ({args.transport} all-reduce of 2*K*N+1 doubles per iteration)" if world > 1 else "none"},
+                       "sharding": f"rows/{world} ({transport} all-reduce of 2*K*N+1 doubles per iteration)" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,

@@ -39,22 +39,40 @@ def global_init(M, N, K, random_state, W_init=None, H_init=None):
 
 
 def attach_comm(ctx, dist, transport="rccl"):
-    """Join `ctx` to the job described by the initialised torch.distributed module `dist`."""
+    """Join `ctx` to the job described by the initialised torch.distributed module `dist`.
+
+    transport "rccl": RCCL all-reduce on the library's stream (the product path).
+    transport "host": all-reduce through pinned host memory and gloo (tests, rehearsal on one GPU).
+    transport "auto": try RCCL; if any rank fails to load librccl the whole job agrees (one gloo
+    all-reduce of a flag) to use the host transport instead of dying.  Returns the transport used.
+    """
+    import torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    if transport == "rccl":
-        uid = [_hip.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], world, rank)
-    elif transport == "host":
-        import torch
 
+    def host():
         def allreduce(arr):
-            t = torch.from_numpy(arr)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-
+            dist.all_reduce(torch.from_numpy(arr), op=dist.ReduceOp.SUM)
         ctx.comm_init_host(allreduce, world, rank)
-    else:
+        return "host"
+
+    if transport == "host":
+        return host()
+    if transport not in ("rccl", "auto"):
         raise ValueError(f"unknown transport {transport!r}")
+    uid, err = None, None
+    if rank == 0:
+        try:
+            uid = _hip.comm_unique_id()
+        except _hip.NBMFHipError as e:       # librccl could not be loaded
+            err = str(e)
+    box = [uid]
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        if transport == "rccl":
+            raise _hip.NBMFHipError(f"RCCL unavailable on rank 0: {err}")
+        return host()
+    ctx.comm_init(box[0], world, rank)
+    return "rccl"
 
 
 def fit_row_sharded(Y_local, M_global, r0, n_components, dist, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,

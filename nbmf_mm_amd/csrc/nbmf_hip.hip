@@ -129,13 +129,14 @@ struct PassArgs {
 };
 
 template <int KB, int DATA, int MODE>
-__global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a) {
+__global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pass_kernel(PassArgs a) {
   constexpr int K = 16 * KB;
   constexpr int S = K / 4;            // Theta k-steps
-  constexpr int NB = 8 / KB;          // row blocks per LDS stage
+  constexpr int NB = 8 / KB;          // row blocks per LDS stage (32 KiB)
   constexpr int BLK = K * 16;         // doubles per block per operand image
+  constexpr bool U8 = (NB * BLK / 2) / 256 == 8;   // 16-byte pieces per thread per image: 4, or 8 at K = 128
   constexpr int STAGE_D = 2 * NB * BLK;   // doubles per stage: [NB][T image] then [NB][G image] (= 32 KB)
-  constexpr int N2 = NB * BLK / 2;    // double2 per image per stage (= 1024)
+  constexpr int N2 = NB * BLK / 2;    // double2 per image per stage (1024, or 2048 at K = 128)
   extern __shared__ __attribute__((aligned(16))) double lds[];   // two stages (double buffer)
 
   if (*a.done) return;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
   //      to the other LDS buffer after the current stage's math, one barrier per stage.
   // (macros over named scalars, not lambdas/arrays: hipcc leaves such an array in scratch memory once
   //  register pressure rises)
-  double2 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7;
+  double2 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7, sr8, sr9, sr10, sr11, sr12, sr13, sr14, sr15;
   uint32_t cnext[NB];
 #define STAGE_LOAD(RB)                                                          \
   {                                                                             \
@@ -187,6 +188,16 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
     sr5 = srcG_[256];                                                           \
     sr6 = srcG_[512];                                                           \
     sr7 = srcG_[768];                                                           \
+    if (U8) {                                                                   \
+      sr8 = srcT_[1024];                                                        \
+      sr9 = srcT_[1280];                                                        \
+      sr10 = srcT_[1536];                                                       \
+      sr11 = srcT_[1792];                                                       \
+      sr12 = srcG_[1024];                                                       \
+      sr13 = srcG_[1280];                                                       \
+      sr14 = srcG_[1536];                                                       \
+      sr15 = srcG_[1792];                                                       \
+    }                                                                           \
     if (DATA == DATA_BIN) {                                                     \
       _Pragma("unroll") for (int b_ = 0; b_ < NB; ++b_) cnext[b_] = codes[(size_t)((RB) + b_) * 64]; \
     }                                                                           \
@@ -202,6 +213,16 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
     dst_[N2 + 256] = sr5;                                                       \
     dst_[N2 + 512] = sr6;                                                       \
     dst_[N2 + 768] = sr7;                                                       \
+    if (U8) {                                                                   \
+      dst_[1024] = sr8;                                                         \
+      dst_[1280] = sr9;                                                         \
+      dst_[1536] = sr10;                                                        \
+      dst_[1792] = sr11;                                                        \
+      dst_[N2 + 1024] = sr12;                                                   \
+      dst_[N2 + 1280] = sr13;                                                   \
+      dst_[N2 + 1536] = sr14;                                                   \
+      dst_[N2 + 1792] = sr15;                                                   \
+    }                                                                           \
   }
 
   uint32_t ccur[NB];
@@ -219,32 +240,51 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
     __builtin_amdgcn_sched_barrier(0);   // keep the loads here: hipcc otherwise sinks each one next to its ds_write
     const double* base = lds + buf * STAGE_D;
 
-    double lt[S];
+    // Operand fragments are pulled from LDS in groups of (at most) 8, one group ahead of the MFMAs that
+    // use them (8 x 64 cycles of MFMA cover the LDS latency); keeps the fragment registers at 4 x 16.
+    constexpr int GT = (S < 8) ? S : 8;          // Theta k-steps per group
+    constexpr int NGT = S / GT;
+    constexpr int PB = 4 * KB;                   // back-product operands per tile, order p = r*KB + kb
+    constexpr int GB = (PB < 8) ? PB : 8;
+    constexpr int NGB = PB / GB;
+    double tcur[GT];
 #pragma unroll
-    for (int s = 0; s < S; ++s) lt[s] = base[s * 64 + lane];
+    for (int i = 0; i < GT; ++i) tcur[i] = base[i * 64 + lane];
 
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+      const double* ldsT = base + b * BLK;
       const double* ldsG = base + NB * BLK + b * BLK;
-      // back-product operands of this tile: issued before the Theta chain, consumed after it
-      double lg[4 * KB][4];
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lg[kb][r] = ldsG[(kb * 4 + r) * 64 + lane];
-      __builtin_amdgcn_sched_barrier(0);   // LDS reads stay ahead of the Theta chain that hides their latency
 
-      // ---- Theta tile: rows 16(rb+b)+4r+q, column 16cb+c in register r of lane (q,c)
-      d4 th = {0, 0, 0, 0};
+      // ---- Theta tile: rows 16(rb+b)+4r+q, column 16cb+c in register r of lane (q,c).
+      // (two interleaved accumulation chains: a dependent f64 MFMA issues ~10 % slower than an
+      //  independent one when the SIMD's other wave is not there to fill the gap)
+      d4 th = {0, 0, 0, 0}, th2 = {0, 0, 0, 0};
 #pragma unroll
-      for (int s = 0; s < S; ++s) th = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[s], rf[s], th, 0, 0, 0);
-
-      // Theta operands of the next tile of this stage
-      if (b + 1 < NB) {
+      for (int g = 0; g < NGT; ++g) {
+        double tnxt[GT];
+        if (g + 1 < NGT) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) lt[s] = base[(b + 1) * BLK + s * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);
+          for (int i = 0; i < GT; ++i) tnxt[i] = ldsT[((g + 1) * GT + i) * 64 + lane];
+          __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs that hide them
+        }
+#pragma unroll
+        for (int i = 0; i < GT; i += 2) {
+          th = __builtin_amdgcn_mfma_f64_16x16x4f64(tcur[i], rf[g * GT + i], th, 0, 0, 0);
+          th2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tcur[i + 1], rf[g * GT + i + 1], th2, 0, 0, 0);
+        }
+        if (g + 1 < NGT) {
+#pragma unroll
+          for (int i = 0; i < GT; ++i) tcur[i] = tnxt[i];
+        }
       }
+      th += th2;
+
+      // first back-product operand group: issued now, lands during the ratio arithmetic
+      double gcur[GB];
+#pragma unroll
+      for (int i = 0; i < GB; ++i) gcur[i] = ldsG[((i % KB) * 4 + (i / KB)) * 64 + lane];
+      __builtin_amdgcn_sched_barrier(0);
 
       // ---- ratios
       double R1[4], R2[4];
@@ -312,11 +352,30 @@ __global__ __launch_bounds__(256, (KB <= 4 ? 2 : 1)) void pass_kernel(PassArgs a
 
       // ---- back-products: accumulator registers of Theta are the B operands (rows 4r..4r+3)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int g = 0; g < NGB; ++g) {
+        double gnxt[GB];
+        if (g + 1 < NGB) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          acc1[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(lg[kb][r], R1[r], acc1[kb], 0, 0, 0);
-          if (MODE == MODE_H) acc2[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(lg[kb][r], R2[r], acc2[kb], 0, 0, 0);
+          for (int i = 0; i < GB; ++i) {
+            const int p = (g + 1) * GB + i;
+            gnxt[i] = ldsG[((p % KB) * 4 + (p / KB)) * 64 + lane];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (b + 1 < NB) {
+          // last group: fetch the first Theta group of the next tile of this stage
+#pragma unroll
+          for (int i = 0; i < GT; ++i) tcur[i] = base[(b + 1) * BLK + i * 64 + lane];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+          const int p = g * GB + i, r = p / KB, kb = p % KB;
+          acc1[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(gcur[i], R1[r], acc1[kb], 0, 0, 0);
+          if (MODE == MODE_H) acc2[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(gcur[i], R2[r], acc2[kb], 0, 0, 0);
+        }
+        if (g + 1 < NGB) {
+#pragma unroll
+          for (int i = 0; i < GB; ++i) gcur[i] = gnxt[i];
         }
       }
     }
@@ -838,7 +897,12 @@ constexpr int kNcclSum = 0;       // ncclSum
 template <int KB, int DATA, int MODE>
 hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
   dim3 grid(a.Cb / WG_WAVES, chunks);
-  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE>), grid, dim3(256), 2 * STAGE_BYTES, st, a);
+  constexpr int lds_bytes = 2 * STAGE_BYTES;
+  if (lds_bytes > 65536) {
+    hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE>), grid, dim3(256), lds_bytes, st, a);
   return hipGetLastError();
 }
 
