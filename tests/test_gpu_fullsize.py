@@ -1,0 +1,91 @@
+"""BASELINE-size checks (V 65536 x 8192, K=64, 90 % observed) through properties that do not need
+a full CPU run: slice-exact parity (the H-update of a column subset depends only on those columns,
+the W-update of a row subset only on those rows), additivity of the log-likelihood over row shards,
+monotone loss, simplex/range constraints and bitwise run-to-run determinism."""
+import numpy as np
+import pytest
+
+from oracle import nbmf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+M, N, K = 65536, 8192, 64
+ALPHA, BETA, EPS = 1.2, 1.2, 1e-8
+
+
+@pytest.fixture(scope="module")
+def problem():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_shard, init_factors
+    X, Mk = make_shard(M, N, 0, M, seed=0)
+    W0, H0 = init_factors(M, N, K, seed=0)
+    return X, Mk, W0, H0
+
+
+def _prior(H):
+    return (ALPHA - 1) * np.sum(np.log(H + EPS)) + (BETA - 1) * np.sum(np.log(1 - H + EPS))
+
+
+def test_full_size_iteration_properties(problem):
+    from nbmf_mm_amd import _hip
+    X, Mk, W0, H0 = problem
+    with _hip.Context(M, N, K) as ctx:
+        ctx.set_hyper(ALPHA, BETA, EPS)
+        assert ctx.upload(X, mask=Mk) is True                      # 1 byte/entry path
+        n_obs = ctx.n_obs()
+        assert n_obs == float(np.count_nonzero(Mk))
+        ctx.set_factors(W0, H0)
+        loss_init = ctx.loss()
+        losses1, _ = ctx.run(1, 0.0)
+        W1, H1 = ctx.get_factors()
+        # ---- slice-exact parity of one whole iteration against the oracle
+        cols = np.random.default_rng(1).choice(N, 192, replace=False)
+        rows = np.random.default_rng(2).choice(M, 384, replace=False)
+        Ym = X[:, cols] * Mk[:, cols]
+        theta = W0.T @ H0[:, cols]
+        num = H0[:, cols] * (W0 @ (Ym / (theta + EPS))) + (ALPHA - 1)
+        den = (1 - H0[:, cols]) * (W0 @ ((1 - Ym) / (1 - theta + EPS))) + (BETA - 1)
+        H_ref = np.clip(num / (num + den + EPS), EPS, 1 - EPS)
+        np.testing.assert_allclose(H1[:, cols], H_ref, rtol=0, atol=1e-12)
+        Yr, Mr = X[rows], Mk[rows].astype(np.float64)
+        th_t = H1.T @ W0[:, rows]
+        Wn = W0[:, rows] * (H1 @ ((Yr.T * Mr.T) / (th_t + EPS)) + (1 - H1) @ (((1 - Yr).T * Mr.T) / (1 - th_t + EPS)))
+        Wn = Wn / N
+        Wn = Wn / Wn.sum(axis=0, keepdims=True)
+        np.testing.assert_allclose(W1[:, rows], Wn, rtol=0, atol=1e-12)
+        # ---- constraints
+        np.testing.assert_allclose(W1.sum(axis=0), 1.0, atol=1e-12)
+        assert H1.min() >= EPS and H1.max() <= 1 - EPS
+        # ---- more iterations: monotone, and bitwise reproducible from the same state
+        more, _ = ctx.run(6, 0.0)
+        curve = np.concatenate([[loss_init], losses1, more])
+        assert all(curve[i] <= curve[i - 1] + 1e-12 for i in range(1, len(curve)))
+        Wa, Ha = ctx.get_factors()
+        ctx.set_factors(W1, H1)
+        again, _ = ctx.run(6, 0.0)
+        Wb, Hb = ctx.get_factors()
+        np.testing.assert_array_equal(more, again)
+        np.testing.assert_array_equal(Wa, Wb)
+        np.testing.assert_array_equal(Ha, Hb)
+        full_loss = curve[-1]
+
+    # ---- additivity of the log-likelihood over row shards ("checksum of checksums"), and one shard
+    #      against the oracle
+    ll_total, nobs_total = 0.0, 0.0
+    bounds = [(0, 2048), (2048, 20000), (20000, 47001), (47001, M)]
+    for (r0, r1) in bounds:
+        with _hip.Context(r1 - r0, N, K) as sh:
+            sh.set_hyper(ALPHA, BETA, EPS)
+            sh.upload(X[r0:r1], mask=Mk[r0:r1])
+            sh.set_factors(np.ascontiguousarray(Wa[:, r0:r1]), Ha)
+            li, ni = sh.loss(), sh.n_obs()
+            ll_total += -li * ni - _prior(Ha)
+            nobs_total += ni
+            if r0 == 0:
+                want = orc.mm_loss(X[r0:r1], np.ascontiguousarray(Wa[:, r0:r1]), Ha, Mk[r0:r1].astype(np.float64),
+                                   ALPHA, BETA, EPS)
+                assert abs(li - want) <= 1e-12 * abs(want)
+    assert nobs_total == n_obs
+    assembled = -(ll_total + _prior(Ha)) / nobs_total
+    assert abs(assembled - full_loss) <= 1e-12 * abs(full_loss)
