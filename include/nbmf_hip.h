@@ -92,6 +92,11 @@ int nbmf_w_only_steps(nbmf_ctx* ctx, int n_steps);
 /* Loss of the current factors, _solver.py:148-162. */
 int nbmf_loss(nbmf_ctx* ctx, double* loss);
 
+/* Sum over entries of Ym*log(Theta+eps) + (1-Ym)*log(1-Theta+eps) for the current factors (summed over
+ * ranks when a communicator is attached): the numerator of NBMFMM.score, _base.py:239-247 (divide by
+ * nbmf_get_n_obs), and the data term of the loss, _solver.py:150-154. */
+int nbmf_loglik(nbmf_ctx* ctx, double* loglik);
+
 /* Multi-GPU (row-sharded Y): rank 0 calls nbmf_comm_unique_id and distributes the 128 bytes; every
  * rank then calls nbmf_comm_init.  After it, nbmf_run all-reduces the k x n H-step products
  * [P1|P2|loglik] over RCCL each iteration and uses the global observed count.  No reference

@@ -6,7 +6,7 @@ import numpy as np
 from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array
 
-from ._solver import nbmf_mm_solver, w_only_transform
+from ._solver import device_score, nbmf_mm_solver, w_only_transform
 from ._utils import check_is_fitted
 
 # exact-string alias table of src/nbmf_mm/_base.py:127-137 (not case-folding)
@@ -131,18 +131,22 @@ class NBMFMM(BaseEstimator, TransformerMixin):
         As in the reference the inner ``transform`` is called WITHOUT the mask (:235)."""
         check_is_fitted(self, ["components_"])
         X = self._validated(X)
+        if mask is not None and hasattr(mask, "toarray"):
+            mask = mask.toarray()
+        H = np.asarray(self.components_, dtype=np.float64)
+        if H.min() >= 0.0 and H.max() <= 1.0:
+            return device_score(X, H, mask=mask, n_iter=50, device=self.device)
+        # components_ outside [0, 1] (set by hand): the clip of inverse_transform matters -> host formula
         recon = self.inverse_transform(self.transform(X))
         eps = 1e-8
         if mask is None:
             ll = X * np.log(recon + eps) + (1 - X) * np.log(1 - recon + eps)
             n_obs = X.size
         else:
-            if hasattr(mask, "toarray"):
-                mask = mask.toarray()
             xm = X * mask
             ll = xm * np.log(recon + eps) + (1 - xm) * np.log(1 - recon + eps)
             n_obs = np.count_nonzero(mask)
-        return np.sum(ll) / n_obs
+        return float(np.sum(ll) / n_obs)
 
     def perplexity(self, X, mask=None):
         """exp(-score) (_base.py:249-265)."""

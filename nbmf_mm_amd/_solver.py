@@ -125,3 +125,28 @@ def w_only_transform(X, H, mask=None, W0=None, n_iter=50, device=0):
     W = np.clip(W, 1e-8, 1.0)                          # :196
     W = W / W.sum(axis=1, keepdims=True)               # :198
     return W
+
+
+def device_score(X, H, mask=None, n_iter=50, device=0):
+    """``NBMFMM.score`` on the GPU (src/nbmf_mm/_base.py:212-247): the inner transform runs WITHOUT
+    the mask (:235), then the mean log-likelihood per observed entry of W @ H under ``mask``.
+    The reference clips W @ H to [0, 1] (:210); with rows of W on the simplex and H in [0, 1] the
+    product already lies there up to rounding, so the clip is not applied on the device."""
+    X = np.asarray(X, dtype=np.float64)
+    m, n = X.shape
+    k = H.shape[0]
+    W0 = np.random.uniform(0.1, 0.9, (m, k))          # global RNG, :175
+    with _hip.Context(m, n, k, device=device) as ctx:
+        ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_NORMALIZE)
+        ctx.upload(X, mask=None, transposed=False)
+        ctx.set_factors(np.ascontiguousarray(W0.T), H)
+        ctx.w_only_steps(int(n_iter))
+        Wk, _ = ctx.get_factors()
+        W = np.clip(Wk.T, 1e-8, 1.0)                  # :196
+        W = W / W.sum(axis=1, keepdims=True)          # :198
+        if mask is not None:
+            ctx.upload(X, mask=mask, transposed=False)
+        ctx.set_factors(np.ascontiguousarray(W.T), H)
+        ll = ctx.loglik()
+        n_obs = ctx.n_obs()
+    return float(ll / n_obs)

@@ -1028,14 +1028,14 @@ int enqueue_h_pass(nbmf_ctx* c) {
   return NBMF_OK;
 }
 
-int enqueue_finalize(nbmf_ctx* c, int t, double tol) {
+int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false) {
   const long long per = (long long)c->KP * c->nA;
   const bool sharded = c->comm || c->host_reduce;
   const double* ll_src = sharded ? c->Pbuf + 2 * per : c->lossbuf;
   const int n_ll = sharded ? 1 : c->chunksH * (int)(c->nA / 16);
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, ll_src, n_ll, sharded ? 0.0 : ll_pad_of(c),
-                     c->prior, c->n_prior_blocks, c->alpha - 1.0, c->beta - 1.0, c->n_obs_global, c->losses_d, t, tol,
-                     c->scal, c->flags);
+                     c->prior, c->n_prior_blocks, loglik_only ? 0.0 : c->alpha - 1.0, loglik_only ? 0.0 : c->beta - 1.0,
+                     loglik_only ? -1.0 : c->n_obs_global, c->losses_d, t, tol, c->scal, c->flags);
   HIPCHK(hipGetLastError());
   return NBMF_OK;
 }
@@ -1457,6 +1457,20 @@ int nbmf_loss(nbmf_ctx* c, double* loss) {
   if (int rc = enqueue_h_pass(c)) return rc;
   if (int rc = enqueue_finalize(c, 0, 0.0)) return rc;
   HIPCHK(hipMemcpyAsync(loss, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->timing) timing_collect(c);
+  return NBMF_OK;
+}
+
+int nbmf_loglik(nbmf_ctx* c, double* loglik) {
+  if (int rc = ready(c)) return rc;
+  if (!loglik) return fail(NBMF_ERR_ARG, "null output");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_losses(c, 1)) return rc;
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
+  if (int rc = enqueue_h_pass(c)) return rc;
+  if (int rc = enqueue_finalize(c, 0, 0.0, /*loglik_only=*/true)) return rc;   // -(ll + 0 + 0) / -1 = ll
+  HIPCHK(hipMemcpyAsync(loglik, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->timing) timing_collect(c);
   return NBMF_OK;

@@ -200,10 +200,19 @@ def test_transform_score_perplexity(hip, golden):
     assert abs(sc - float(g["score"])) <= 5e-3 * abs(float(g["score"]))
     np.random.seed(6)
     W_pin = orc.w_only_transform(X, g["H"])
-    mdl.transform = lambda X_, mask=None: W_pin
-    assert abs(mdl.score(X, mask=maskf) - float(g["score"])) <= 1e-12 * abs(float(g["score"]))
-    assert abs(mdl.score(X) - float(g["score_nomask"])) <= 1e-12 * abs(float(g["score_nomask"]))
-    assert abs(mdl.perplexity(X, mask=maskf) - float(g["perplexity"])) <= 1e-12 * float(g["perplexity"])
+    for mk, key in [(maskf, "score"), (None, "score_nomask")]:
+        with hip.Context(100, 500, 6) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            ctx.upload(X, mask=mk)
+            ctx.set_factors(np.ascontiguousarray(W_pin.T), g["H"])
+            dev = ctx.loglik() / ctx.n_obs()
+        assert abs(dev - float(g[key])) <= 1e-12 * abs(float(g[key]))
+    np.random.seed(6)
+    assert abs(mdl.perplexity(X, mask=maskf) - float(g["perplexity"])) <= 5e-3 * float(g["perplexity"])
+    # components_ outside [0,1] (set by hand) takes the host formula with the reference's clip
+    mdl.components_ = g["H"] * 1.5
+    np.random.seed(6)
+    assert np.isfinite(mdl.score(X))
 
 
 def test_midsize_curves(hip, golden):
