@@ -93,3 +93,70 @@ def fit_row_sharded(Y_local, M_global, r0, n_components, dist, max_iter=500, tol
         losses, n_iter = ctx.run(int(max_iter), float(tol))
         Wk, Hk = ctx.get_factors()
     return Wk.T, Hk, [float(v) for v in losses], n_iter
+
+
+def fit_sharded(V_local, global_shape, offset, n_components, dist, orientation="beta-dir", max_iter=500, tol=1e-5,
+                alpha=1.2, beta=1.2, W_init=None, H_init=None, mask_local=None, random_state=None, eps=1e-8,
+                projection="normalize", device=0, transport="rccl"):
+    """Sharded fit in the user's orientation.  The shard axis is the one the SIMPLEX factor indexes,
+    i.e. the rows of the internal matrix (src/nbmf_mm/_solver.py:113-123):
+
+      * ``beta-dir``: ``V_local = V[offset:offset+m_loc, :]`` (row shard); returns
+        ``(W_local (m_loc,k), H (k,N), losses, n_iter)``;
+      * ``dir-beta``: ``V_local = V[:, offset:offset+n_loc]`` (column shard, since the internal problem
+        is V.T); returns ``(W (M,k), H_local (k,n_loc), losses, n_iter)``.
+
+    (Row-sharding V under dir-beta would move the all-reduce into the W-step; not built.)
+    Custom inits follow the reference: under dir-beta they are swapped only if BOTH are given.
+    """
+    from ._solver import _projection_code
+    V_local = np.asarray(V_local, dtype=np.float64)
+    M, N = global_shape
+    K = int(n_components)
+    if orientation == "beta-dir":
+        if V_local.shape[1] != N:
+            raise ValueError(f"beta-dir shard must hold full rows: got {V_local.shape}, global {global_shape}")
+        return fit_row_sharded(V_local, M, offset, K, dist, max_iter=max_iter, tol=tol, alpha=alpha, beta=beta,
+                               W_init=W_init, H_init=H_init, mask_local=mask_local, random_state=random_state,
+                               eps=eps, projection=projection, device=device, transport=transport)
+    if orientation != "dir-beta":
+        raise ValueError(f"Unknown orientation: {orientation}")
+    if V_local.shape[0] != M:
+        raise ValueError(f"dir-beta shard must hold full columns: got {V_local.shape}, global {global_shape}")
+    n_loc = V_local.shape[1]
+    if W_init is not None and H_init is not None:          # swap only if both given, _solver.py:122-123
+        W_init, H_init = np.asarray(H_init).T, np.asarray(W_init).T
+    # internal problem: Y = V.T is (N x M); its rows [offset, offset+n_loc) live here
+    Wi, Hi = global_init(N, M, K, random_state, W_init, H_init)       # Wi (K,N) simplex, Hi (K,M) Beta
+    with _hip.Context(n_loc, M, K, device=device) as ctx:
+        ctx.set_hyper(alpha, beta, eps, _projection_code(projection))
+        ctx.upload(V_local, mask=mask_local, transposed=True)          # the pack kernel applies the transpose
+        ctx.set_factors(np.ascontiguousarray(Wi[:, offset:offset + n_loc]), Hi)
+        attach_comm(ctx, dist, transport)
+        losses, n_iter = ctx.run(int(max_iter), float(tol))
+        Wk, Hk = ctx.get_factors()
+    # un-transpose (_solver.py:182-184): W_out = H_int.T (M,k), H_out = W_int (k, n_loc)
+    return Hk.T, Wk, [float(v) for v in losses], n_iter
+
+
+def fit_restarts(V, n_components, dist, n_init, random_state=0, device=0, **solver_kwargs):
+    """``n_init`` independent restarts spread over the ranks (replicas: every rank holds all of V and
+    runs restarts rank, rank+world, ... with seeds random_state + i); the best final loss wins and its
+    factors are broadcast.  Returns ``(W, H, losses, n_iter, best_index)`` on every rank."""
+    from ._solver import nbmf_mm_solver
+    world, rank = dist.get_world_size(), dist.get_rank()
+    best = None
+    for i in range(rank, int(n_init), world):
+        res = nbmf_mm_solver(V, n_components, random_state=random_state + i, device=device, **solver_kwargs)
+        if best is None or res[2][-1] < best[1][2][-1]:
+            best = (i, res)
+    mine = (float("inf"), -1) if best is None else (float(best[1][2][-1]), best[0])
+    table = [None] * world
+    dist.all_gather_object(table, mine)
+    win_rank = min(range(world), key=lambda r: (table[r][0], table[r][1]))
+    payload = [None]
+    if rank == win_rank:
+        _, (W, H, losses, _, n_iter) = best
+        payload = [(W, H, losses, n_iter, best[0])]
+    dist.broadcast_object_list(payload, src=win_rank)
+    return payload[0]

@@ -26,6 +26,26 @@ def _problem():
     return M, N, K, Y, mask
 
 
+def _worker_dirbeta_restarts(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    from nbmf_mm_amd import _dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        M, N, K, Y, mask = _problem()
+        V, Vmask = Y[:300, :], mask[:300, :]                 # dir-beta on a 300 x 333 matrix, column shards
+        c0, c1 = _dist.shard_bounds(V.shape[1], world, rank)
+        W, Hl, losses, n_iter = _dist.fit_sharded(V[:, c0:c1], V.shape, c0, 9, dist, orientation="dir-beta",
+                                                  max_iter=25, tol=0, mask_local=Vmask[:, c0:c1], random_state=4,
+                                                  device=0, transport="host")
+        best = _dist.fit_restarts(V, 9, dist, n_init=3, random_state=10, device=0, max_iter=15, tol=0, mask=Vmask)
+        q.put((rank, c0, c1, W, Hl, losses, best))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -106,3 +126,35 @@ def test_rccl_single_rank():
         assert ctx.n_obs() == np.count_nonzero(mask)
         losses, n_iter = ctx.run(10, 0.0)
     np.testing.assert_array_equal(losses, np.array(l1))
+
+
+def test_dir_beta_column_shards_and_parallel_restarts():
+    import torch.multiprocessing as mp
+    from nbmf_mm_amd import nbmf_mm_solver
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dirbeta_restarts, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    M, N, K, Y, mask = _problem()
+    V, Vmask = Y[:300, :], mask[:300, :]
+    W1, H1, l1, _, _ = nbmf_mm_solver(V, 9, max_iter=25, tol=0, mask=Vmask, random_state=4, orientation="dir-beta")
+    H = np.concatenate([r[4] for r in res], axis=1)
+    np.testing.assert_allclose(H, H1, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(H.sum(axis=0), 1.0, atol=1e-12)          # dir-beta: columns of H on the simplex
+    for r in res:
+        np.testing.assert_allclose(r[3], W1, rtol=0, atol=1e-12)        # Beta factor replicated
+        np.testing.assert_allclose(r[5], l1, rtol=1e-10, atol=0)
+    # restarts: both ranks agree on the winner, which equals the best of the three sequential runs
+    seq = [nbmf_mm_solver(V, 9, max_iter=15, tol=0, mask=Vmask, random_state=10 + i) for i in range(3)]
+    k = int(np.argmin([s_[2][-1] for s_ in seq]))
+    for r in res:
+        Wb, Hb, lb, nb, ib = r[6]
+        assert ib == k and nb == 15
+        np.testing.assert_array_equal(Wb, seq[k][0])
+        np.testing.assert_array_equal(lb, seq[k][2])
