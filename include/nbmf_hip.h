@@ -97,6 +97,11 @@ int nbmf_loss(nbmf_ctx* ctx, double* loss);
  * nbmf_get_n_obs), and the data term of the loss, _solver.py:150-154. */
 int nbmf_loglik(nbmf_ctx* ctx, double* loglik);
 
+/* Strictly masked variant: sum over OBSERVED entries only of mask*(Y log(Theta+eps) + (1-Y) log(1-Theta+eps)),
+ * the held-out log-likelihood of examples/reproduce_magron2022.py:40-47 (compute_perplexity: divide by
+ * nbmf_get_n_obs, negate, exponentiate).  A Theta-only sweep (no back-products). */
+int nbmf_loglik_strict(nbmf_ctx* ctx, double* loglik);
+
 /* Multi-GPU (row-sharded Y): rank 0 calls nbmf_comm_unique_id and distributes the 128 bytes; every
  * rank then calls nbmf_comm_init.  After it, nbmf_run all-reduces the k x n H-step products
  * [P1|P2|loglik] over RCCL each iteration and uses the global observed count.  No reference

@@ -29,7 +29,7 @@ MAX_K = 128
 SYMBOLS = [
     "nbmf_abi_version", "nbmf_last_error", "nbmf_device_count", "nbmf_create", "nbmf_destroy",
     "nbmf_set_hyper", "nbmf_upload", "nbmf_get_n_obs", "nbmf_set_factors", "nbmf_get_factors",
-    "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_loglik", "nbmf_comm_unique_id", "nbmf_comm_init",
+    "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_loglik", "nbmf_loglik_strict", "nbmf_comm_unique_id", "nbmf_comm_init",
     "nbmf_comm_init_host",
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_rcp",
 ]
@@ -76,6 +76,7 @@ def load():
     lib.nbmf_w_only_steps.argtypes = [c_void_p, c_int]
     lib.nbmf_loss.argtypes = [c_void_p, dp]
     lib.nbmf_loglik.argtypes = [c_void_p, dp]
+    lib.nbmf_loglik_strict.argtypes = [c_void_p, dp]
     lib.nbmf_comm_unique_id.argtypes = [c_void_p]
     lib.nbmf_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
     lib.nbmf_comm_init_host.argtypes = [c_void_p, HOST_ALLREDUCE_FN, c_void_p, c_int, c_int]
@@ -201,6 +202,12 @@ class Context:
         """Data log-likelihood sum of the current factors (no prior, not divided by n_obs)."""
         v = c_double(0)
         _check(self._lib.nbmf_loglik(self._h, byref(v)))
+        return v.value
+
+    def loglik_strict(self):
+        """Log-likelihood summed over observed entries only (held-out perplexity numerator)."""
+        v = c_double(0)
+        _check(self._lib.nbmf_loglik_strict(self._h, byref(v)))
         return v.value
 
     def comm_init(self, uid: bytes, nranks: int, rank: int):

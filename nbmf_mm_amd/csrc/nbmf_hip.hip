@@ -64,7 +64,7 @@ inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 enum { DATA_BIN = 0, DATA_F64 = 1, DATA_F64M = 2 };
-enum { MODE_H = 0, MODE_W = 1 };
+enum { MODE_H = 0, MODE_W = 1, MODE_L = 2 };
 
 // code bits of the binary path
 enum : unsigned { CB_YM = 1u, CB_ZOBS = 2u, CB_VALID = 4u };
@@ -107,6 +107,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 //   Rf     the factor indexed by D's columns (stationary in registers, T form)
 //   MODE_H: out1 = L (R1), out2 = L (R2)                  (P1, P2 of _solver.py:42-43)
 //   MODE_W: out1 = L (S1 - S2) + column sums of S2         (the bracket of _solver.py:53)
+//   MODE_L: no products; strictly masked log-likelihood only (held-out perplexity, evaluation)
 // Workgroup = 4 waves; wave w owns column strip 4*blockIdx.x + w and sweeps row blocks
 // [chunk*CH, chunk*CH + CH).  Partial results go to per-chunk slabs (ordered reduction later: no
 // atomics, bitwise reproducible).
@@ -282,8 +283,13 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
 
       // first back-product operand group: issued now, lands during the ratio arithmetic
       double gcur[GB];
+      if (MODE != MODE_L) {
 #pragma unroll
-      for (int i = 0; i < GB; ++i) gcur[i] = ldsG[((i % KB) * 4 + (i / KB)) * 64 + lane];
+        for (int i = 0; i < GB; ++i) gcur[i] = ldsG[((i % KB) * 4 + (i / KB)) * 64 + lane];
+      } else if (b + 1 < NB) {
+#pragma unroll
+        for (int i = 0; i < GT; ++i) tcur[i] = base[(b + 1) * BLK + i * 64 + lane];
+      }
       __builtin_amdgcn_sched_barrier(0);
 
       // ---- ratios
@@ -301,6 +307,13 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
           const double z = mk_double(0u, ~m & 0x3FF00000u);
           const double sg = mk_double(0u, (~m & 0x80000000u) | 0x3FF00000u);
           const double d = __builtin_fma(sg, th[r], z) + eps;
+          if (MODE == MODE_L) {
+            // strictly masked likelihood: only observed entries (ones or zeros) enter the product
+            const uint32_t keep = m | (uint32_t)(-(int)((code >> (8 * r + 1)) & 1u));
+            dd[r] = mk_double((uint32_t)__double2loint(d) & keep,
+                              ((uint32_t)__double2hiint(d) & keep) | (~keep & 0x3FF00000u));   // keep ? d : 1.0
+            continue;
+          }
           const double rr = rcp_nr(d);
           dd[r] = d;
           const uint32_t rlo = (uint32_t)__double2loint(rr), rhi = (uint32_t)__double2hiint(rr);
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
             s2 += mk_double(rlo & zo, rhi & zo);
           }
         }
-        if (MODE == MODE_H) {
+        if (MODE == MODE_H || MODE == MODE_L) {
           prod *= (dd[0] * dd[1]) * (dd[2] * dd[3]);   // >= 1e-32 per tile: no underflow before frexp
           int e;
           prod = frexp(prod, &e);
@@ -334,7 +347,11 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
           const double t = th[r];
           const double t1 = t + eps;
           const double t2 = (1.0 - t) + eps;
-          if (MODE == MODE_H) {
+          if (MODE == MODE_L) {
+            // mask * (Y log(Theta+eps) + (1-Y) log(1-Theta+eps)): examples/reproduce_magron2022.py:40-47
+            const double wgt = (DATA == DATA_F64M) ? m4[r] : 1.0;
+            llsum += (valid && wgt != 0.0) ? wgt * (y * log(t1) + (1.0 - y) * log(t2)) : 0.0;
+          } else if (MODE == MODE_H) {
             const double ym = (DATA == DATA_F64M) ? y * m4[r] : y;    // Y*mask, _solver.py:30
             R1[r] = valid ? ym / t1 : 0.0;                            // :42
             R2[r] = valid ? (1.0 - ym) / t2 : 0.0;                    // :43 (1 - Y*mask)
@@ -351,6 +368,7 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
       }
 
       // ---- back-products: accumulator registers of Theta are the B operands (rows 4r..4r+3)
+      if (MODE != MODE_L) {
 #pragma unroll
       for (int g = 0; g < NGB; ++g) {
         double gnxt[GB];
@@ -378,6 +396,7 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
           for (int i = 0; i < GB; ++i) gcur[i] = gnxt[i];
         }
       }
+      }
     }
 
     // write the prefetched stage into the other buffer; its last readers finished before the previous
@@ -397,6 +416,7 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
   }
   double* o1 = a.out1 + (size_t)chunk * K * a.C_alloc + (size_t)cb * 16 + c;
   double* o2 = (MODE == MODE_H) ? a.out2 + (size_t)chunk * K * a.C_alloc + (size_t)cb * 16 + c : nullptr;
+  if (MODE != MODE_L) {
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
@@ -410,9 +430,10 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
       }
     }
   }
+  }
 #undef STAGE_LOAD
 #undef STAGE_STORE
-  if (MODE == MODE_H) {
+  if (MODE == MODE_H || MODE == MODE_L) {
     double ll;
     if (DATA == DATA_BIN)
       ll = log(prod) + (double)pexp * 0.6931471805599453094;
@@ -1473,6 +1494,39 @@ int nbmf_loglik(nbmf_ctx* c, double* loglik) {
   HIPCHK(hipMemcpyAsync(loglik, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->timing) timing_collect(c);
+  return NBMF_OK;
+}
+
+int nbmf_loglik_strict(nbmf_ctx* c, double* loglik) {
+  if (int rc = ready(c)) return rc;
+  if (!loglik) return fail(NBMF_ERR_ARG, "null output");
+  if (c->comm || c->host_reduce) return fail(NBMF_ERR_STATE, "nbmf_loglik_strict is a single-context evaluation");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_losses(c, 1)) return rc;
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
+  PassArgs a{};
+  a.data = c->dataA;
+  a.mask = c->maskA;
+  a.LT = c->WT;
+  a.LG = c->WG;
+  a.RfT = c->HT;
+  a.out1 = c->slabH;      // unused by MODE_L
+  a.out2 = nullptr;
+  a.lossbuf = c->lossbuf;
+  a.done = c->flags;
+  a.Rb = (int)(c->mA / 16);
+  a.Cb = (int)(c->nA / 16);
+  a.CH = c->CH_H;
+  a.C_alloc = c->nA;
+  a.eps = c->eps;
+  HIPCHK(launch_pass<MODE_L>(c->KB, c->data_kind, a, c->chunksH, c->stream));
+  // ordered sum of the per-wave partials; no pad correction (pad entries are not observed), no prior
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->lossbuf,
+                     c->chunksH * (int)(c->nA / 16), 0.0, c->prior, c->n_prior_blocks, 0.0, 0.0, -1.0, c->losses_d, 0, 0.0,
+                     c->scal, c->flags);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(loglik, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return NBMF_OK;
 }
 

@@ -1,0 +1,67 @@
+"""GPU-resident equivalent of the reference's experiment driver (examples/reproduce_magron2022.py):
+masked training followed by held-out perplexity over a grid of (alpha, beta) prior settings and/or
+component counts K.  The data matrix and each mask are packed onto the device ONCE per K; every grid
+point reuses them (`train_nbmf_mm`, :49-73; `compute_perplexity`, :40-47; the figure loops, :75-340).
+With a torch.distributed group the grid points are dealt round-robin over the ranks (one GPU each).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from . import _hip
+from ._dist import global_init
+
+
+def heldout_perplexity(ctx_eval, W_kxm, H_kxn):
+    """exp(-sum(mask * loglik) / count_nonzero(mask)) of W^T H on the entries `ctx_eval` holds as
+    observed (examples/reproduce_magron2022.py:40-47), evaluated by the Theta-only sweep."""
+    ctx_eval.set_factors(W_kxm, H_kxn)
+    return float(np.exp(-ctx_eval.loglik_strict() / ctx_eval.n_obs()))
+
+
+def perplexity_grid(Y, train_mask, eval_masks, n_components, alphas, betas, max_iter=500, tol=1e-5,
+                    random_state=12345, device=0, dist=None):
+    """Fit beta-dir NBMF-MM on `train_mask` for every (K, alpha, beta) and report held-out perplexities.
+
+    eval_masks: dict name -> mask (e.g. {"val": val_mask, "test": test_mask}).
+    n_components: int or iterable of ints.  Returns a list of dict rows sorted by (K, alpha, beta) with
+    keys K, alpha, beta, n_iter, loss, time, and one perplexity per eval mask; every rank gets all rows.
+    """
+    Y = np.asarray(Y, dtype=np.float64)
+    m, n = Y.shape
+    Ks = [int(n_components)] if np.isscalar(n_components) else [int(k) for k in n_components]
+    points = [(k, float(a), float(b)) for k in Ks for a in alphas for b in betas]
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+    mine = points[rank::world]
+    rows = []
+    for k in sorted({p[0] for p in mine}):
+        with _hip.Context(m, n, k, device=device) as train:
+            train.upload(Y, mask=train_mask)
+            evals = {}
+            try:
+                for name, mk in eval_masks.items():
+                    evals[name] = _hip.Context(m, n, k, device=device)
+                    evals[name].set_hyper(1.0, 1.0, 1e-8)
+                    evals[name].upload(Y, mask=mk)
+                for (_, a, b) in [p for p in mine if p[0] == k]:
+                    W0, H0 = global_init(m, n, k, random_state)        # same init for every grid point
+                    train.set_hyper(a, b, 1e-8, _hip.PROJ_NORMALIZE)
+                    train.set_factors(W0, H0)
+                    t0 = time.perf_counter()
+                    losses, n_iter = train.run(int(max_iter), float(tol))
+                    dt = time.perf_counter() - t0
+                    W, H = train.get_factors()
+                    row = {"K": k, "alpha": a, "beta": b, "n_iter": int(n_iter), "loss": float(losses[-1]), "time": dt}
+                    for name, ev in evals.items():
+                        row[name + "_perplexity"] = heldout_perplexity(ev, W, H)
+                    rows.append(row)
+            finally:
+                for ev in evals.values():
+                    ev.close()
+    if dist is not None and world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rows)
+        rows = [r for part in gathered for r in part]
+    return sorted(rows, key=lambda r: (r["K"], r["alpha"], r["beta"]))

@@ -22,6 +22,7 @@ from __future__ import annotations
 import numpy as np
 
 __all__ = [
+    "heldout_perplexity",
     "mm_step",
     "mm_loss",
     "solve",
@@ -204,6 +205,15 @@ def score(X, W, H, mask=None):
         ll = xm * np.log(recon + eps) + (1 - xm) * np.log(1 - recon + eps)
         n_obs = np.count_nonzero(mask)
     return np.sum(ll) / n_obs
+
+
+def heldout_perplexity(Y, Y_hat, mask=None, eps=1e-8):
+    """Strictly masked perplexity of the reference's experiment script
+    (examples/reproduce_magron2022.py:40-47, `compute_perplexity`)."""
+    if mask is None:
+        mask = np.ones_like(Y)
+    ll = Y * np.log(Y_hat + eps) + (1 - Y) * np.log(1 - Y_hat + eps)
+    return np.exp(-np.sum(mask * ll) / np.count_nonzero(mask))
 
 
 # ----------------------------------------------------------------------------------------

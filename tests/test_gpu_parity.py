@@ -300,3 +300,33 @@ def test_out_of_range_raises(hip):
     with pytest.raises(ValueError):
         from nbmf_mm_amd import nbmf_mm_solver
         nbmf_mm_solver(np.full((20, 10), 1.5), 3, max_iter=2)       # solver-level range check is on the device
+
+
+def test_perplexity_grid_matches_reference_driver(hip):
+    """The experiment driver (examples/reproduce_magron2022.py:40-73 of the reference): train on a
+    train mask, strictly masked held-out perplexity on validation/test masks, over an (alpha, beta, K) grid."""
+    from nbmf_mm_amd.experiments import perplexity_grid
+    r = np.random.default_rng(12)
+    Y = (r.random((253, 302)) < 0.2).astype(np.float64)
+    u = r.random(Y.shape)
+    train, val, test = (u < 0.7).astype(np.float64), ((u >= 0.7) & (u < 0.85)).astype(np.float64), (u >= 0.85).astype(np.float64)
+    rows = perplexity_grid(Y, train, {"val": val, "test": test}, [4, 20], [0.5, 1.5], [1.0, 2.5], max_iter=60, tol=1e-5)
+    assert len(rows) == 8
+    for row in rows:
+        W, H, losses, _, n_iter = orc.solve(Y, row["K"], max_iter=60, tol=1e-5, alpha=row["alpha"], beta=row["beta"],
+                                            mask=train, random_state=12345)
+        assert row["n_iter"] == n_iter
+        assert abs(row["loss"] - losses[-1]) <= 1e-10 * abs(losses[-1])
+        for name, mk in [("val", val), ("test", test)]:
+            want = orc.heldout_perplexity(Y, W @ H, mk)
+            assert abs(row[name + "_perplexity"] - want) <= 1e-9 * want
+    # real-valued data with a weight mask goes through the f64 variant of the same sweep
+    Yr, wts = r.random((40, 70)), r.random((40, 70))
+    Wf = r.uniform(0.1, 0.9, (5, 40)); Wf /= Wf.sum(axis=0, keepdims=True)
+    Hf = r.uniform(0.1, 0.9, (5, 70))
+    with hip.Context(40, 70, 5) as ctx:
+        ctx.upload(Yr, mask=wts)
+        ctx.set_factors(Wf, Hf)
+        got = np.exp(-ctx.loglik_strict() / ctx.n_obs())
+    want = orc.heldout_perplexity(Yr, Wf.T @ Hf, wts)
+    assert abs(got - want) <= 1e-12 * want
