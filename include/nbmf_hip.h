@@ -121,9 +121,12 @@ int nbmf_timing_enable(nbmf_ctx* ctx, int enable);
 int nbmf_timing_get(nbmf_ctx* ctx, double* hpass_ms, int* hpass_launches, double* wpass_ms, int* wpass_launches);
 int nbmf_synchronize(nbmf_ctx* ctx);
 
-/* Self-test hook used by the GPU tests: runs the pass kernel's Newton reciprocal on n caller-supplied
- * denominators and returns the results (compared on the host with IEEE 1/d). */
-int nbmf_selftest_rcp(int device, int n, const double* denominators, double* reciprocals);
+/* Self-test hook used by the GPU tests: applies one of the pass kernel's scalar device routines to n
+ * caller-supplied values (op 0: Newton reciprocal used on the binary path; op 1: the natural logarithm
+ * of the general path) so the host can compare with IEEE 1/x and log(x). */
+#define NBMF_SELFTEST_RCP 0
+#define NBMF_SELFTEST_LOG 1
+int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ SYMBOLS = [
     "nbmf_set_hyper", "nbmf_upload", "nbmf_get_n_obs", "nbmf_set_factors", "nbmf_get_factors",
     "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_loglik", "nbmf_loglik_strict", "nbmf_comm_unique_id", "nbmf_comm_init",
     "nbmf_comm_init_host",
-    "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_rcp",
+    "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
 ]
 
 
@@ -83,7 +83,7 @@ def load():
     lib.nbmf_timing_enable.argtypes = [c_void_p, c_int]
     lib.nbmf_timing_get.argtypes = [c_void_p, dp, POINTER(c_int), dp, POINTER(c_int)]
     lib.nbmf_synchronize.argtypes = [c_void_p]
-    lib.nbmf_selftest_rcp.argtypes = [c_int, c_int, c_void_p, c_void_p]
+    lib.nbmf_selftest_unary.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p]
     for name in SYMBOLS:
         if name != "nbmf_last_error":
             getattr(lib, name).restype = c_int
@@ -247,9 +247,10 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
-def selftest_rcp(denominators, device=0):
-    """Reciprocals of `denominators` computed by the pass kernel's Newton step (GPU tests)."""
-    d = _f64c(denominators).ravel()
+def selftest_unary(op, x, device=0):
+    """Apply a device scalar routine of the pass kernel (0: Newton reciprocal, 1: log) to `x` (GPU tests)."""
+    d = _f64c(x).ravel()
     out = np.empty_like(d)
-    _check(load().nbmf_selftest_rcp(int(device), int(d.size), d.ctypes.data_as(c_void_p), out.ctypes.data_as(c_void_p)))
+    _check(load().nbmf_selftest_unary(int(device), int(op), int(d.size), d.ctypes.data_as(c_void_p),
+                                      out.ctypes.data_as(c_void_p)))
     return out

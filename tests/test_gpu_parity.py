@@ -39,11 +39,26 @@ def test_reciprocal_accuracy(hip):
     r = np.random.default_rng(0)
     d = np.concatenate([np.exp(r.uniform(np.log(1e-8), 0.0, 1 << 20)) + 1e-8, -r.uniform(1e-8, 3.0, 1 << 16),
                         r.uniform(1.0, 50.0, 1 << 16), [1e-8, 1.0 + 1e-8, 2e-8]])
-    got = hip.selftest_rcp(d)
+    got = hip.selftest_unary(0, d)
     want = 1.0 / d
     ulp = np.abs(got - want) / np.spacing(np.abs(want))
     assert ulp.max() <= 1.0, ulp.max()
     assert (ulp == 0).mean() > 0.9
+
+
+def test_log_accuracy(hip):
+    # logarithm of the general path: <= 1 ulp of the correctly rounded value on (0, 2], same special
+    # values as NumPy elsewhere
+    r = np.random.default_rng(1)
+    x = np.concatenate([np.exp(r.uniform(np.log(1e-8), np.log(2.0), 1 << 20)), r.uniform(0.5, 1.5, 1 << 18),
+                        [1.0, 1e-8, 1.0 + 1e-8, 0.5, 2.0, np.nextafter(1.0, 0), np.nextafter(1.0, 2), 1e-300, 1e300]])
+    got = hip.selftest_unary(1, x)
+    want = np.log(x)
+    ulp = np.abs(got - want) / np.maximum(np.spacing(np.abs(want)), 5e-324)
+    assert ulp[want != 0].max() <= 1.0 and (got[want == 0] == 0).all()
+    with np.errstate(all="ignore"):
+        sp = np.array([0.0, -1.0, np.inf, np.nan, 5e-324])
+        np.testing.assert_array_equal(hip.selftest_unary(1, sp), np.log(sp))
 
 
 def test_one_step_golden_vectors(hip, golden):
