@@ -590,11 +590,31 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
                                                        const double* __restrict__ prior, int n_prior, double am1,
                                                        double bm1, double n_obs, double* __restrict__ losses, int t,
                                                        double tol, double* __restrict__ scal, int* __restrict__ flags) {
-  __shared__ double sh4[4];
+  __shared__ double sh[3][4];
   if (flags[0]) return;
-  const double ll = ordered_sum256(ll_src, n_ll, 1, sh4) - ll_pad;
-  const double sa = ordered_sum256(prior, n_prior, 2, sh4);
-  const double sb = ordered_sum256(prior + 1, n_prior, 2, sh4);
+  // three ordered sums in one sweep (same per-thread / butterfly / wave order as ordered_sum256, so the
+  // single-GPU and the all-reduced paths agree bit for bit); the loads of the three streams overlap
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const int n_max = n_ll > n_prior ? n_ll : n_prior;
+  for (int j = threadIdx.x; j < n_max; j += 256) {
+    if (j < n_ll) s0 += ll_src[j];
+    if (j < n_prior) {
+      s1 += prior[2 * (size_t)j];
+      s2 += prior[2 * (size_t)j + 1];
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = s0;
+    sh[1][threadIdx.x >> 6] = s1;
+    sh[2][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  const double ll = (((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3]) - ll_pad;
+  const double sa = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+  const double sb = ((sh[2][0] + sh[2][1]) + sh[2][2]) + sh[2][3];
   if (threadIdx.x == 0) {
     const double A = am1 * sa;
     const double B = bm1 * sb;
