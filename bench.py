@@ -114,7 +114,7 @@ def main():
 
     X, Mk = make_shard(M, N, r0, r1, args.seed, masked=masked)
     W_full, H0 = init_factors(M, N, K, args.seed)
-    ctx = _hip.Context(r1 - r0, N, K, device=0 if args.share_gpu else local_rank)
+    ctx = _hip.Context(r1 - r0, N, K, device=0 if args.share_gpu else local_rank)   # one rank = one GPU
     ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_DUCHI if args.projection == "duchi" else _hip.PROJ_NORMALIZE)
     t_up = time.perf_counter()
     binary_path = ctx.upload(X, mask=Mk)
@@ -126,9 +126,14 @@ def main():
     if world > 1:
         transport = _dist.attach_comm(ctx, dist, args.transport)
 
+    dev = 0 if args.share_gpu else local_rank
+    if torch.cuda.is_available():
+        torch.cuda.set_device(dev)
+
     def sync():
-        ctx.synchronize()
-        torch.cuda.synchronize() if torch.cuda.is_available() and torch.cuda.is_initialized() else None
+        ctx.synchronize()                       # the library's own stream
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(dev)         # whole device (contract: barrier + torch.cuda.synchronize())
         if world > 1:
             dist.barrier()
 

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void h_update_kernel(const double* __restrict_
       const double num = hold * p1 + am1;             // :42
       const double den = (1.0 - hold) * p2 + bm1;     // :43
       h = num / (num + den + eps);                    // :46
-      h = fmin(fmax(h, eps), 1.0 - eps);              // :47
+      h = (h < eps) ? eps : ((h > 1.0 - eps) ? 1.0 - eps : h);   // np.clip, :47 (a NaN stays a NaN, as in NumPy)
       la = log(h + eps);                              // :158
       lb = log(1.0 - h + eps);                        // :159
     }

@@ -345,3 +345,65 @@ def test_perplexity_grid_matches_reference_driver(hip):
         got = np.exp(-ctx.loglik_strict() / ctx.n_obs())
     want = orc.heldout_perplexity(Yr, Wf.T @ Hf, wts)
     assert abs(got - want) <= 1e-12 * want
+
+
+def _vs_oracle(Y, k, mask=None, iters=15, **kw):
+    from nbmf_mm_amd import nbmf_mm_solver
+    W, H, l, _, n1 = nbmf_mm_solver(Y, k, max_iter=iters, tol=0, mask=mask, **kw)
+    Wr, Hr, lr, _, n2 = orc.solve(np.asarray(_dense_any(Y), dtype=np.float64), k, max_iter=iters, tol=0,
+                                  mask=mask, **kw)
+    assert n1 == n2
+    np.testing.assert_allclose(l, lr, rtol=LOSS_RTOL, atol=0)
+    np.testing.assert_allclose(W, Wr, rtol=0, atol=FACTOR_ATOL)
+    np.testing.assert_allclose(H, Hr, rtol=0, atol=FACTOR_ATOL)
+    return W, H, l
+
+
+def _dense_any(a):
+    return a.toarray() if hasattr(a, "toarray") else a
+
+
+def test_edge_cases_vs_oracle(hip):
+    """Degenerate and boundary inputs the domain offers: constant matrices, K larger than the matrix,
+    priors below 1 (negative a, b: the clip is what keeps H in range), rows/columns with nothing
+    observed, a mask observing almost nothing, single row / single column."""
+    r = np.random.default_rng(33)
+    Y = (r.random((37, 53)) < 0.3).astype(np.float64)
+    _vs_oracle(np.zeros((20, 31)), 3, random_state=1)
+    _vs_oracle(np.ones((20, 31)), 3, random_state=1)
+    _vs_oracle(Y[:5, :7], 12, random_state=2)                      # K > min(m, n)
+    _vs_oracle(Y, 4, random_state=3, alpha=0.5, beta=2.0)          # a = -0.5
+    _vs_oracle(Y, 4, random_state=3, alpha=0.3, beta=0.4)          # both negative
+    _vs_oracle(Y[:1, :], 2, random_state=4)                        # one row
+    _vs_oracle(Y[:, :1], 2, random_state=4)                        # one column
+    mask = (r.random(Y.shape) < 0.7).astype(np.float64)
+    mask[5, :] = 0.0                                               # a row never observed
+    mask[:, 11] = 0.0                                              # a column never observed
+    _vs_oracle(Y, 5, mask=mask, random_state=5)
+    _vs_oracle(Y, 5, mask=mask, random_state=5, orientation="dir-beta")
+    sparse_mask = np.zeros_like(Y); sparse_mask[3, 4] = 1.0; sparse_mask[30, 50] = 1.0
+    _vs_oracle(Y, 3, mask=sparse_mask, random_state=6, iters=6)
+    # probabilities exactly at the ends of [0, 1] mixed with interior values -> general path
+    Yp = r.random((30, 40)); Yp[0, :5] = 0.0; Yp[1, :5] = 1.0
+    _vs_oracle(Yp, 4, random_state=7)
+
+
+def test_input_types_accepted_like_the_reference(hip):
+    """scipy CSR data and masks, bool / int data, Fortran-ordered and strided arrays
+    (tests/test_api.py:111-123 and tests/test_public_api.py:125-134 of the reference)."""
+    import scipy.sparse as sp
+    from nbmf_mm_amd import NBMF
+    r = np.random.default_rng(8)
+    X = (r.random((40, 60)) < 0.25).astype(np.float64)
+    mask = r.random((40, 60)) < 0.8
+    base = NBMF(n_components=5, random_state=0, max_iter=12, tol=0).fit(X, mask=mask)
+    for Xv, mv in [(sp.csr_matrix(X), sp.csr_matrix(mask.astype(np.float64))), (X.astype(bool), mask),
+                   (X.astype(np.int64), mask.astype(np.int32)), (np.asfortranarray(X), np.asfortranarray(mask)),
+                   (np.repeat(X, 2, axis=1)[:, ::2], mask.astype(np.float32))]:
+        got = NBMF(n_components=5, random_state=0, max_iter=12, tol=0).fit(Xv, mask=mv)
+        np.testing.assert_array_equal(got.components_, base.components_)
+        np.testing.assert_array_equal(got.loss_curve_, base.loss_curve_)
+    # dir-beta with a strided (transposed-view) input
+    a = NBMF(n_components=5, random_state=0, max_iter=8, tol=0, orientation="dir-beta").fit(X.T.copy().T)
+    b = NBMF(n_components=5, random_state=0, max_iter=8, tol=0, orientation="dir-beta").fit(X)
+    np.testing.assert_array_equal(a.W_, b.W_)
