@@ -153,6 +153,7 @@ struct PassArgs {
   int CH;               // row blocks per chunk (multiple of NB)
   long long C_alloc;    // 16*Cb
   double eps;
+  int strict;           // MODE_L: 1 = only observed entries enter the likelihood; 0 = the loss's semantics (as MODE_H)
 };
 
 template <int KB, int DATA, int MODE>
@@ -334,8 +335,9 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
           const double sg = mk_double(0u, (~m & 0x80000000u) | 0x3FF00000u);
           const double d = __builtin_fma(sg, th[r], z) + eps;
           if (MODE == MODE_L) {
-            // strictly masked likelihood: only observed entries (ones or zeros) enter the product
-            const uint32_t keep = m | (uint32_t)(-(int)((code >> (8 * r + 1)) & 1u));
+            // strict: only observed entries (ones or zeros) enter the product; otherwise every entry
+            // does, exactly as in MODE_H (pad entries are divided out later)
+            const uint32_t keep = a.strict ? (m | (uint32_t)(-(int)((code >> (8 * r + 1)) & 1u))) : 0xFFFFFFFFu;
             dd[r] = mk_double((uint32_t)__double2loint(d) & keep,
                               ((uint32_t)__double2hiint(d) & keep) | (~keep & 0x3FF00000u));   // keep ? d : 1.0
             continue;
@@ -374,9 +376,14 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
           const double t1 = t + eps;
           const double t2 = (1.0 - t) + eps;
           if (MODE == MODE_L) {
-            // mask * (Y log(Theta+eps) + (1-Y) log(1-Theta+eps)): examples/reproduce_magron2022.py:40-47
-            const double wgt = (DATA == DATA_F64M) ? m4[r] : 1.0;
-            llsum += (valid && wgt != 0.0) ? wgt * (y * log_fast(t1) + (1.0 - y) * log_fast(t2)) : 0.0;
+            if (a.strict) {
+              // mask * (Y log(Theta+eps) + (1-Y) log(1-Theta+eps)): examples/reproduce_magron2022.py:40-47
+              const double wgt = (DATA == DATA_F64M) ? m4[r] : 1.0;
+              llsum += (valid && wgt != 0.0) ? wgt * (y * log_fast(t1) + (1.0 - y) * log_fast(t2)) : 0.0;
+            } else {
+              const double ym = (DATA == DATA_F64M) ? y * m4[r] : y;
+              llsum += valid ? (ym * log_fast(t1) + (1.0 - ym) * log_fast(t2)) : 0.0;   // as MODE_H, :150,154
+            }
           } else if (MODE == MODE_H) {
             const double ym = (DATA == DATA_F64M) ? y * m4[r] : y;    // Y*mask, _solver.py:30
             R1[r] = valid ? ym / t1 : 0.0;                            // :42
@@ -507,6 +514,15 @@ __global__ __launch_bounds__(256) void reduce_h_kernel(const double* __restrict_
     const double s = ordered_sum256(lossbuf, n_loss, 1, sh4);
     if (threadIdx.x == 0) Pbuf[2 * per] = s - ll_pad;   // binary path: pad entries each contributed log(1+eps)
   }
+}
+
+// Sharded evaluation sweeps: ordered sum of the log-likelihood partials into the all-reduce slot.
+__global__ __launch_bounds__(256) void ll_reduce_kernel(const double* __restrict__ lossbuf, int n_loss, double ll_pad,
+                                                        double* __restrict__ out, const int* done) {
+  __shared__ double sh4[4];
+  if (*done) return;
+  const double s = ordered_sum256(lossbuf, n_loss, 1, sh4);
+  if (threadIdx.x == 0) *out = s - ll_pad;
 }
 
 // Beta log-prior sums of H (natural layout), per-block partials -> prior[blk][2] (_solver.py:158-159).
@@ -1095,6 +1111,45 @@ int enqueue_h_pass(nbmf_ctx* c) {
   return NBMF_OK;
 }
 
+// Theta-only sweep (no back-products): the log-likelihood of the current factors at a third of the
+// H-pass's MFMA work; the per-wave partials land in lossbuf exactly as an H-pass leaves them.
+int enqueue_loglik_pass(nbmf_ctx* c, int strict) {
+  PassArgs a{};
+  a.data = c->dataA;
+  a.mask = c->maskA;
+  a.LT = c->WT;
+  a.LG = c->WG;
+  a.RfT = c->HT;
+  a.out1 = c->slabH;      // unused
+  a.out2 = nullptr;
+  a.lossbuf = c->lossbuf;
+  a.done = c->flags;
+  a.Rb = (int)(c->mA / 16);
+  a.Cb = (int)(c->nA / 16);
+  a.CH = c->CH_H;
+  a.C_alloc = c->nA;
+  a.eps = c->eps;
+  a.strict = strict;
+  HIPCHK(launch_pass<MODE_L>(c->KB, c->data_kind, a, c->chunksH, c->stream));
+  if (c->comm || c->host_reduce) {
+    // sharded: only the scalar travels (same slot of Pbuf that the H-pass payload uses for it)
+    double* tail = c->Pbuf + 2 * (size_t)c->KP * c->nA;
+    hipLaunchKernelGGL(ll_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->lossbuf,
+                       c->chunksH * a.Cb, strict ? 0.0 : ll_pad_of(c), tail, c->flags);
+    HIPCHK(hipGetLastError());
+    if (c->comm) {
+      NCCLCHK(g_rccl.AllReduce(tail, tail, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    } else {
+      HIPCHK(hipMemcpyAsync(c->host_buf, tail, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->host_reduce(c->host_reduce_user, c->host_buf, 1) != 0)
+        return fail(NBMF_ERR_COMM, "host all-reduce callback failed");
+      HIPCHK(hipMemcpyAsync(tail, c->host_buf, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+  }
+  return NBMF_OK;
+}
+
 int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false) {
   const long long per = (long long)c->KP * c->nA;
   const bool sharded = c->comm || c->host_reduce;
@@ -1486,7 +1541,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
     }
   }
   if (!host_done) {
-    if (int rc = enqueue_h_pass(c)) return rc;                    // loss of the last iteration
+    if (int rc = enqueue_loglik_pass(c, 0)) return rc;            // loss of the last iteration (Theta-only sweep)
     if (int rc = enqueue_finalize(c, max_iter - 1, tol)) return rc;
   }
   int fl[2];
@@ -1521,7 +1576,7 @@ int nbmf_loss(nbmf_ctx* c, double* loss) {
   hipLaunchKernelGGL(prior_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Hn, c->prior, c->k, c->KP,
                      (long long)c->n, (long long)c->nA, c->eps);
   HIPCHK(hipGetLastError());
-  if (int rc = enqueue_h_pass(c)) return rc;
+  if (int rc = enqueue_loglik_pass(c, 0)) return rc;
   if (int rc = enqueue_finalize(c, 0, 0.0)) return rc;
   HIPCHK(hipMemcpyAsync(loss, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1535,7 +1590,7 @@ int nbmf_loglik(nbmf_ctx* c, double* loglik) {
   if (int rc = set_device(c)) return rc;
   if (int rc = ensure_losses(c, 1)) return rc;
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
-  if (int rc = enqueue_h_pass(c)) return rc;
+  if (int rc = enqueue_loglik_pass(c, 0)) return rc;
   if (int rc = enqueue_finalize(c, 0, 0.0, /*loglik_only=*/true)) return rc;   // -(ll + 0 + 0) / -1 = ll
   HIPCHK(hipMemcpyAsync(loglik, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1546,30 +1601,16 @@ int nbmf_loglik(nbmf_ctx* c, double* loglik) {
 int nbmf_loglik_strict(nbmf_ctx* c, double* loglik) {
   if (int rc = ready(c)) return rc;
   if (!loglik) return fail(NBMF_ERR_ARG, "null output");
-  if (c->comm || c->host_reduce) return fail(NBMF_ERR_STATE, "nbmf_loglik_strict is a single-context evaluation");
   if (int rc = set_device(c)) return rc;
   if (int rc = ensure_losses(c, 1)) return rc;
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
-  PassArgs a{};
-  a.data = c->dataA;
-  a.mask = c->maskA;
-  a.LT = c->WT;
-  a.LG = c->WG;
-  a.RfT = c->HT;
-  a.out1 = c->slabH;      // unused by MODE_L
-  a.out2 = nullptr;
-  a.lossbuf = c->lossbuf;
-  a.done = c->flags;
-  a.Rb = (int)(c->mA / 16);
-  a.Cb = (int)(c->nA / 16);
-  a.CH = c->CH_H;
-  a.C_alloc = c->nA;
-  a.eps = c->eps;
-  HIPCHK(launch_pass<MODE_L>(c->KB, c->data_kind, a, c->chunksH, c->stream));
+  if (int rc = enqueue_loglik_pass(c, 1)) return rc;
   // ordered sum of the per-wave partials; no pad correction (pad entries are not observed), no prior
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->lossbuf,
-                     c->chunksH * (int)(c->nA / 16), 0.0, c->prior, c->n_prior_blocks, 0.0, 0.0, -1.0, c->losses_d, 0, 0.0,
-                     c->scal, c->flags);
+  const bool sharded = c->comm || c->host_reduce;
+  const double* ll_src = sharded ? c->Pbuf + 2 * (size_t)c->KP * c->nA : c->lossbuf;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, ll_src,
+                     sharded ? 1 : c->chunksH * (int)(c->nA / 16), 0.0, c->prior, c->n_prior_blocks, 0.0, 0.0, -1.0,
+                     c->losses_d, 0, 0.0, c->scal, c->flags);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(loglik, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -407,3 +407,24 @@ def test_input_types_accepted_like_the_reference(hip):
     a = NBMF(n_components=5, random_state=0, max_iter=8, tol=0, orientation="dir-beta").fit(X.T.copy().T)
     b = NBMF(n_components=5, random_state=0, max_iter=8, tol=0, orientation="dir-beta").fit(X)
     np.testing.assert_array_equal(a.W_, b.W_)
+
+
+def test_last_loss_sweep_is_bitwise_the_fused_one(hip):
+    """The loss of the final iteration comes from the Theta-only sweep, every earlier one from the fused
+    H-pass of the following iteration; both must give the same bits (so a run of k iterations is a prefix
+    of a run of k+1), on the binary and on the general storage path, K = 64 and K = 128."""
+    r = np.random.default_rng(3)
+    for (m, n, k, real) in [(300, 260, 64, False), (150, 140, 128, False), (90, 200, 20, True)]:
+        Y = r.random((m, n)) if real else (r.random((m, n)) < 0.3).astype(np.float64)
+        mask = r.random((m, n)) < 0.9
+        W0 = r.uniform(0.1, 0.9, (k, m)); W0 /= W0.sum(axis=0, keepdims=True)
+        H0 = r.uniform(0.1, 0.9, (k, n))
+        with hip.Context(m, n, k) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            ctx.upload(Y, mask=mask)
+            ctx.set_factors(W0, H0)
+            a, _ = ctx.run(5, 0.0)
+            assert a[-1] == ctx.loss()
+            ctx.set_factors(W0, H0)
+            b, _ = ctx.run(6, 0.0)
+        np.testing.assert_array_equal(a, b[:5])
