@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--no-mask", action="store_true")
     ap.add_argument("--projection", default="duchi", choices=["normalize", "duchi"])
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: --M rows PER GPU (e.g. --M 32768 --gpus 8 = BASELINE configs[3], 262144 x 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host"],
                     help="all-reduce transport for --gpus > 1 (host = gloo through pinned memory; tests only)")
@@ -107,7 +109,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    M, N, K = args.M, args.N, args.K
+    M, N, K = (args.M * world if args.weak else args.M), args.N, args.K
     masked = not args.no_mask
     from nbmf_mm_amd import _dist
     r0, r1 = _dist.shard_bounds(M, world, rank)
@@ -164,7 +166,7 @@ def main():
         out = {
             "metric": "MM-iterations/sec", "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "final_nll_per_entry": float(losses[-1]),
             "loss_monotone": bool(all(losses[i] <= losses[i - 1] + 1e-12 for i in range(1, len(losses)))),
             "config": {"workload": f"NBMF-MM fit, dense binary V {M}x{N} (float64 API, density 0.25), K={K}, "

@@ -1339,9 +1339,10 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   const int64_t U = transposed ? c->n : c->m, V = transposed ? c->m : c->n;
   if (ldx < V || (mask && ldmask < V)) return fail(NBMF_ERR_ARG, "leading dimension smaller than the row length");
 
-  // cheap host-side guess of the storage path from a sample (the device pack verifies it exactly)
-  bool guess_bin = true;
-  {
+  // cheap host-side guess of the storage path from a sample (the device pack verifies it exactly);
+  // NBMF_FORCE_F64=1 keeps binary data on the 8-byte path (measurement only)
+  bool guess_bin = !(getenv("NBMF_FORCE_F64") && atoi(getenv("NBMF_FORCE_F64")) != 0);
+  if (guess_bin) {
     const int64_t rows = U < 8 ? U : 8;
     for (int64_t u = 0; u < rows && guess_bin; ++u) {
       const int64_t uu = (U - 1) * u / (rows > 1 ? rows - 1 : 1);
