@@ -1364,7 +1364,9 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   }
 
   const size_t tiles = (size_t)(c->mA / 16) * (c->nA / 16);
-  const int64_t chunk_rows_max = std::max<int64_t>(PAD, ((int64_t)(256ll << 20) / (V * 8)) / PAD * PAD);
+  // staging chunk: <= 256 MiB of raw rows and <= 32768 tile rows (grid.y limit of the pack launch)
+  const int64_t chunk_rows_max =
+      std::min<int64_t>(32768 * 16, std::max<int64_t>(PAD, ((int64_t)(256ll << 20) / (V * 8)) / PAD * PAD));
   double* raw = nullptr;
   void* rawm = nullptr;
   const size_t msz = mask_kind == NBMF_MASK_F64 ? 8 : 1;

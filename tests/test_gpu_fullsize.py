@@ -89,3 +89,53 @@ def test_full_size_iteration_properties(problem):
     assert nobs_total == n_obs
     assembled = -(ll_total + _prior(Ha)) / nobs_total
     assert abs(assembled - full_loss) <= 1e-12 * abs(full_loss)
+
+
+def test_tall_narrow_and_wide_short_shapes():
+    """Index ranges at the extremes: 1.2 M x 24 (more pack tile-rows than one launch's grid.y holds)
+    and its transpose through dir-beta; both against each other (the transpose identity is bitwise)
+    and a row sample against the oracle's W-step."""
+    from nbmf_mm_amd import nbmf_mm_solver
+    r = np.random.default_rng(5)
+    Mt, Nt, Kt = 1_200_003, 24, 5
+    V = (r.random((Mt, Nt)) < 0.3).astype(np.float64)
+    W, H, l, _, _ = nbmf_mm_solver(V, Kt, max_iter=4, tol=0, random_state=1)
+    H2, W2, l2, _, _ = nbmf_mm_solver(V.T, Kt, max_iter=4, tol=0, random_state=1, orientation="dir-beta")
+    np.testing.assert_array_equal(l, l2)
+    np.testing.assert_array_equal(W, W2.T)
+    np.testing.assert_array_equal(H, H2.T)
+    np.testing.assert_allclose(W.sum(axis=1), 1.0, atol=1e-12)
+    assert all(l[i] <= l[i - 1] + 1e-12 for i in range(1, len(l)))
+    # one more iteration from the returned state, checked on a row sample (the W-update is row-local)
+    rows = r.choice(Mt, 500, replace=False)
+    from nbmf_mm_amd import _hip
+    with _hip.Context(Mt, Nt, Kt) as ctx:
+        ctx.set_hyper(1.2, 1.2)
+        ctx.upload(V)
+        ctx.set_factors(np.ascontiguousarray(W.T), H)
+        ctx.run(1, 0.0)
+        W1, H1 = ctx.get_factors()
+    th_t = H1.T @ W.T[:, rows]
+    Yr = V[rows]
+    Wn = W.T[:, rows] * (H1 @ (Yr.T / (th_t + EPS)) + (1 - H1) @ ((1 - Yr).T / (1 - th_t + EPS)))
+    Wn = Wn / Nt
+    Wn = Wn / Wn.sum(axis=0, keepdims=True)
+    np.testing.assert_allclose(W1[:, rows], Wn, rtol=0, atol=1e-12)
+
+
+def test_k128_dir_beta_large():
+    """configs[4]-like orientation and K at a size one GPU runs in seconds: V 24576 x 12288, K=128,
+    dir-beta, masked; transpose identity against beta-dir on V.T (bitwise), constraints, monotone loss."""
+    from nbmf_mm_amd import nbmf_mm_solver
+    r = np.random.default_rng(6)
+    V = (r.random((24576, 12288)) < 0.05).astype(np.float64)
+    mask = r.random(V.shape) < 0.9
+    W, H, l, _, _ = nbmf_mm_solver(V, 128, max_iter=5, tol=0, random_state=2, orientation="dir-beta", mask=mask)
+    Ht, Wt, lt, _, _ = nbmf_mm_solver(np.ascontiguousarray(V.T), 128, max_iter=5, tol=0, random_state=2,
+                                      mask=np.ascontiguousarray(mask.T))
+    np.testing.assert_array_equal(l, lt)
+    np.testing.assert_array_equal(W, Wt.T)
+    np.testing.assert_array_equal(H, Ht.T)
+    np.testing.assert_allclose(H.sum(axis=0), 1.0, atol=1e-12)          # dir-beta: columns of H on the simplex
+    assert W.min() >= 1e-8 and W.max() <= 1 - 1e-8
+    assert all(l[i] <= l[i - 1] + 1e-12 for i in range(1, len(l)))
