@@ -102,18 +102,25 @@ int nbmf_loglik(nbmf_ctx* ctx, double* loglik);
  * nbmf_get_n_obs, negate, exponentiate).  A Theta-only sweep (no back-products). */
 int nbmf_loglik_strict(nbmf_ctx* ctx, double* loglik);
 
-/* Multi-GPU (row-sharded Y): rank 0 calls nbmf_comm_unique_id and distributes the 128 bytes; every
- * rank then calls nbmf_comm_init.  After it, nbmf_run all-reduces the k x n H-step products
- * [P1|P2|loglik] over RCCL each iteration and uses the global observed count.  No reference
- * counterpart (the reference is single-process). */
+/* Multi-GPU, one process (and one context) per GPU.  The internal matrix Y is split over the ranks along
+ *   shard_axis 0: its ROWS    -> W[:, rows] is local, H is replicated; each iteration all-reduces the k x n
+ *                 H-step products [P1 | P2 | loglik] (2*K*N+1 doubles) before the H-update;
+ *   shard_axis 1: its COLUMNS -> H[:, cols] is local, W is replicated; each iteration all-reduces the k x m
+ *                 W-step bracket (K*M doubles) before the W-update, and [loglik, prior A, prior B] (3 doubles)
+ *                 before the stop test.
+ * (beta-dir with V split by rows, or dir-beta with V split by columns, is axis 0; the other two
+ * combinations are axis 1.)  Rank 0 calls nbmf_comm_unique_id and distributes the 128 bytes; every rank,
+ * after nbmf_upload of its shard, calls nbmf_comm_init.  The global observed count (and, for axis 1, the
+ * global column count and per-row observed counts) are reduced there.  No reference counterpart (the
+ * reference is single-process). */
 int nbmf_comm_unique_id(void* id128);
-int nbmf_comm_init(nbmf_ctx* ctx, const void* id128, int nranks, int rank);
+int nbmf_comm_init(nbmf_ctx* ctx, const void* id128, int nranks, int rank, int shard_axis);
 
 /* Same sharded run with the all-reduce done by the caller on a host buffer (sum over ranks, in place,
  * return 0 on success).  Used by the tests (two ranks sharing one GPU, gloo) and as a fallback
  * transport; the device work and the control flow are identical to the RCCL path. */
 typedef int (*nbmf_host_allreduce_fn)(void* user, double* buf, int64_t count);
-int nbmf_comm_init_host(nbmf_ctx* ctx, nbmf_host_allreduce_fn fn, void* user, int nranks, int rank);
+int nbmf_comm_init_host(nbmf_ctx* ctx, nbmf_host_allreduce_fn fn, void* user, int nranks, int rank, int shard_axis);
 
 /* Measurement: HIP-event timing of the two fused pass kernels on the context's stream. */
 int nbmf_timing_enable(nbmf_ctx* ctx, int enable);

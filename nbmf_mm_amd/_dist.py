@@ -38,7 +38,7 @@ def global_init(M, N, K, random_state, W_init=None, H_init=None):
     return np.ascontiguousarray(W), np.ascontiguousarray(H_init, dtype=np.float64)
 
 
-def attach_comm(ctx, dist, transport="rccl"):
+def attach_comm(ctx, dist, transport="rccl", shard_axis=0):
     """Join `ctx` to the job described by the initialised torch.distributed module `dist`.
 
     transport "rccl": RCCL all-reduce on the library's stream (the product path).
@@ -52,7 +52,7 @@ def attach_comm(ctx, dist, transport="rccl"):
     def host():
         def allreduce(arr):
             dist.all_reduce(torch.from_numpy(arr), op=dist.ReduceOp.SUM)
-        ctx.comm_init_host(allreduce, world, rank)
+        ctx.comm_init_host(allreduce, world, rank, shard_axis)
         return "host"
 
     if transport == "host":
@@ -71,7 +71,7 @@ def attach_comm(ctx, dist, transport="rccl"):
         if transport == "rccl":
             raise _hip.NBMFHipError(f"RCCL unavailable on rank 0: {err}")
         return host()
-    ctx.comm_init(box[0], world, rank)
+    ctx.comm_init(box[0], world, rank, shard_axis)
     return "rccl"
 
 
@@ -95,48 +95,50 @@ def fit_row_sharded(Y_local, M_global, r0, n_components, dist, max_iter=500, tol
     return Wk.T, Hk, [float(v) for v in losses], n_iter
 
 
-def fit_sharded(V_local, global_shape, offset, n_components, dist, orientation="beta-dir", max_iter=500, tol=1e-5,
-                alpha=1.2, beta=1.2, W_init=None, H_init=None, mask_local=None, random_state=None, eps=1e-8,
-                projection="normalize", device=0, transport="rccl"):
-    """Sharded fit in the user's orientation.  The shard axis is the one the SIMPLEX factor indexes,
-    i.e. the rows of the internal matrix (src/nbmf_mm/_solver.py:113-123):
+def fit_sharded(V_local, global_shape, offset, n_components, dist, orientation="beta-dir", shard="rows",
+                max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None, H_init=None, mask_local=None,
+                random_state=None, eps=1e-8, projection="normalize", device=0, transport="rccl"):
+    """Sharded fit in the user's orientation, V split over the ranks by ``shard`` = "rows"
+    (``V_local = V[offset:offset+len, :]``) or "cols" (``V_local = V[:, offset:offset+len]``).
 
-      * ``beta-dir``: ``V_local = V[offset:offset+m_loc, :]`` (row shard); returns
-        ``(W_local (m_loc,k), H (k,N), losses, n_iter)``;
-      * ``dir-beta``: ``V_local = V[:, offset:offset+n_loc]`` (column shard, since the internal problem
-        is V.T); returns ``(W (M,k), H_local (k,n_loc), losses, n_iter)``.
-
-    (Row-sharding V under dir-beta would move the all-reduce into the W-step; not built.)
-    Custom inits follow the reference: under dir-beta they are swapped only if BOTH are given.
+    Which internal axis that is (internal Y = V for beta-dir, V.T for dir-beta, _solver.py:113-123):
+      beta-dir/rows and dir-beta/cols split the rows of Y   -> exchange in the H-step (shard_axis 0);
+      beta-dir/cols and dir-beta/rows split the columns of Y -> exchange in the W-step (shard_axis 1).
+    The factor indexed by the split axis comes back as this rank's slice, the other one whole:
+    returns ``(W, H, losses, n_iter)`` with W (rows_here, k) and H (k, cols_here).
+    Custom inits are GLOBAL arrays; under dir-beta they are swapped only if BOTH are given (:122-123).
     """
     from ._solver import _projection_code
     V_local = np.asarray(V_local, dtype=np.float64)
     M, N = global_shape
     K = int(n_components)
-    if orientation == "beta-dir":
-        if V_local.shape[1] != N:
-            raise ValueError(f"beta-dir shard must hold full rows: got {V_local.shape}, global {global_shape}")
-        return fit_row_sharded(V_local, M, offset, K, dist, max_iter=max_iter, tol=tol, alpha=alpha, beta=beta,
-                               W_init=W_init, H_init=H_init, mask_local=mask_local, random_state=random_state,
-                               eps=eps, projection=projection, device=device, transport=transport)
-    if orientation != "dir-beta":
+    if orientation not in ("beta-dir", "dir-beta"):
         raise ValueError(f"Unknown orientation: {orientation}")
-    if V_local.shape[0] != M:
-        raise ValueError(f"dir-beta shard must hold full columns: got {V_local.shape}, global {global_shape}")
-    n_loc = V_local.shape[1]
-    if W_init is not None and H_init is not None:          # swap only if both given, _solver.py:122-123
+    if shard not in ("rows", "cols"):
+        raise ValueError(f"shard must be 'rows' or 'cols', got {shard!r}")
+    if shard == "rows" and V_local.shape[1] != N or shard == "cols" and V_local.shape[0] != M:
+        raise ValueError(f"shard {V_local.shape} does not span the unsplit axis of the global {global_shape}")
+    transposed = orientation == "dir-beta"
+    m_int, n_int = (N, M) if transposed else (M, N)                  # internal Y is m_int x n_int
+    if transposed and W_init is not None and H_init is not None:
         W_init, H_init = np.asarray(H_init).T, np.asarray(W_init).T
-    # internal problem: Y = V.T is (N x M); its rows [offset, offset+n_loc) live here
-    Wi, Hi = global_init(N, M, K, random_state, W_init, H_init)       # Wi (K,N) simplex, Hi (K,M) Beta
-    with _hip.Context(n_loc, M, K, device=device) as ctx:
+    Wi, Hi = global_init(m_int, n_int, K, random_state, W_init, H_init)   # Wi (K, m_int) simplex, Hi (K, n_int) Beta
+    split_rows_of_Y = (shard == "rows") != transposed                # axis 0 of the internal matrix
+    length = V_local.shape[0] if shard == "rows" else V_local.shape[1]
+    sl = slice(offset, offset + length)
+    if split_rows_of_Y:
+        ctx_shape, W0, H0, axis = (length, n_int), Wi[:, sl], Hi, 0
+    else:
+        ctx_shape, W0, H0, axis = (m_int, length), Wi, Hi[:, sl], 1
+    with _hip.Context(ctx_shape[0], ctx_shape[1], K, device=device) as ctx:
         ctx.set_hyper(alpha, beta, eps, _projection_code(projection))
-        ctx.upload(V_local, mask=mask_local, transposed=True)          # the pack kernel applies the transpose
-        ctx.set_factors(np.ascontiguousarray(Wi[:, offset:offset + n_loc]), Hi)
-        attach_comm(ctx, dist, transport)
+        ctx.upload(V_local, mask=mask_local, transposed=transposed)    # the pack kernel applies the transpose
+        ctx.set_factors(np.ascontiguousarray(W0), np.ascontiguousarray(H0))
+        attach_comm(ctx, dist, transport, shard_axis=axis)
         losses, n_iter = ctx.run(int(max_iter), float(tol))
         Wk, Hk = ctx.get_factors()
-    # un-transpose (_solver.py:182-184): W_out = H_int.T (M,k), H_out = W_int (k, n_loc)
-    return Hk.T, Wk, [float(v) for v in losses], n_iter
+    W_out, H_out = (Hk.T, Wk) if transposed else (Wk.T, Hk)           # un-transpose, _solver.py:178-184
+    return W_out, H_out, [float(v) for v in losses], n_iter
 
 
 def fit_restarts(V, n_components, dist, n_init, random_state=0, device=0, **solver_kwargs):

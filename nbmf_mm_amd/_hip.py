@@ -78,8 +78,8 @@ def load():
     lib.nbmf_loglik.argtypes = [c_void_p, dp]
     lib.nbmf_loglik_strict.argtypes = [c_void_p, dp]
     lib.nbmf_comm_unique_id.argtypes = [c_void_p]
-    lib.nbmf_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
-    lib.nbmf_comm_init_host.argtypes = [c_void_p, HOST_ALLREDUCE_FN, c_void_p, c_int, c_int]
+    lib.nbmf_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int]
+    lib.nbmf_comm_init_host.argtypes = [c_void_p, HOST_ALLREDUCE_FN, c_void_p, c_int, c_int, c_int]
     lib.nbmf_timing_enable.argtypes = [c_void_p, c_int]
     lib.nbmf_timing_get.argtypes = [c_void_p, dp, POINTER(c_int), dp, POINTER(c_int)]
     lib.nbmf_synchronize.argtypes = [c_void_p]
@@ -210,11 +210,12 @@ class Context:
         _check(self._lib.nbmf_loglik_strict(self._h, byref(v)))
         return v.value
 
-    def comm_init(self, uid: bytes, nranks: int, rank: int):
+    def comm_init(self, uid: bytes, nranks: int, rank: int, shard_axis: int = 0):
+        """Attach an RCCL communicator; shard_axis 0 = rows of the internal Y are split, 1 = columns."""
         buf = ctypes.create_string_buffer(bytes(uid), 128)
-        _check(self._lib.nbmf_comm_init(self._h, buf, int(nranks), int(rank)))
+        _check(self._lib.nbmf_comm_init(self._h, buf, int(nranks), int(rank), int(shard_axis)))
 
-    def comm_init_host(self, allreduce, nranks: int, rank: int):
+    def comm_init_host(self, allreduce, nranks: int, rank: int, shard_axis: int = 0):
         """Attach a host-mediated all-reduce: ``allreduce(arr)`` must sum the float64 NumPy array
         ``arr`` over all ranks IN PLACE (e.g. gloo).  Same device work as the RCCL path."""
         def _cb(_user, ptr, count):
@@ -227,7 +228,7 @@ class Context:
                 traceback.print_exc()
                 return 1
         self._host_cb = HOST_ALLREDUCE_FN(_cb)          # keep alive as long as the context
-        _check(self._lib.nbmf_comm_init_host(self._h, self._host_cb, None, int(nranks), int(rank)))
+        _check(self._lib.nbmf_comm_init_host(self._h, self._host_cb, None, int(nranks), int(rank), int(shard_axis)))
 
     def timing_enable(self, on=True):
         _check(self._lib.nbmf_timing_enable(self._h, int(bool(on))))

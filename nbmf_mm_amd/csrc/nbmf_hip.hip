@@ -516,6 +516,30 @@ __global__ __launch_bounds__(256) void reduce_h_kernel(const double* __restrict_
   }
 }
 
+// Column-sharded runs: ordered sums of the Beta log-prior partials into the scalar exchange slot.
+__global__ __launch_bounds__(256) void prior_reduce_kernel(const double* __restrict__ prior, int n_prior,
+                                                           double* __restrict__ out2, const int* done) {
+  __shared__ double sh4[4];
+  if (*done) return;
+  const double a = ordered_sum256(prior, n_prior, 2, sh4);
+  const double b = ordered_sum256(prior + 1, n_prior, 2, sh4);
+  if (threadIdx.x == 0) {
+    out2[0] = a;
+    out2[1] = b;
+  }
+}
+
+// Column-sharded runs: ordered sum of the W-pass slabs into the all-reduce payload Qbuf[k][i].
+__global__ __launch_bounds__(256) void reduce_w_kernel(const double* __restrict__ slab, double* __restrict__ Qbuf,
+                                                       int chunks, long long per, const int* done) {
+  if (*done) return;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per) return;
+  double s = 0;
+  for (int ch = 0; ch < chunks; ++ch) s += slab[(size_t)ch * per + i];
+  Qbuf[i] = s;
+}
+
 // Sharded evaluation sweeps: ordered sum of the log-likelihood partials into the all-reduce slot.
 __global__ __launch_bounds__(256) void ll_reduce_kernel(const double* __restrict__ lossbuf, int n_loss, double ll_pad,
                                                         double* __restrict__ out, const int* done) {
@@ -922,6 +946,13 @@ struct nbmf_ctx {
   double* host_buf = nullptr;   // pinned
   size_t host_buf_count = 0;
   int nranks = 1, rank = 0;
+  // which internal axis is split over the ranks: 0 = rows of Y (W local, H replicated, exchange in the
+  // H-step); 1 = columns of Y (H local, W replicated, exchange in the W-step)
+  int shard_axis = 0;
+  double n_div_global = 0;      // axis 1: global number of internal columns (the "/ n" of _solver.py:54)
+  double* Qbuf = nullptr;       // axis 1: reduced W-step bracket [KP][mA], the all-reduce payload
+  double* sbuf = nullptr;       // scalar exchange slot: [loglik, prior A, prior B]
+  const double* ll_ptr = nullptr;   // where the most recent sweep left the (global) log-likelihood
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;   // pairs
@@ -1063,6 +1094,23 @@ void timing_collect(nbmf_ctx* c) {
   c->ev_used = 0;
 }
 
+// In-place sum over ranks of `count` doubles at device pointer `p`, on the context's stream.
+int all_reduce_inplace(nbmf_ctx* c, double* p, size_t count) {
+  if (c->comm) {
+    NCCLCHK(g_rccl.AllReduce(p, p, count, kNcclFloat64, kNcclSum, c->comm, c->stream));
+  } else if (c->host_reduce) {
+    if (count > c->host_buf_count) return fail(NBMF_ERR_STATE, "internal: host exchange buffer too small");
+    HIPCHK(hipMemcpyAsync(c->host_buf, p, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->host_reduce(c->host_reduce_user, c->host_buf, (int64_t)count) != 0)
+      return fail(NBMF_ERR_COMM, "host all-reduce callback failed");
+    HIPCHK(hipMemcpyAsync(p, c->host_buf, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  return NBMF_OK;
+}
+
+inline bool is_sharded(const nbmf_ctx* c) { return c->comm || c->host_reduce; }
+
 // Binary path: the H-pass multiplies every entry of the padded mA x nA grid into the likelihood
 // product; a pad entry has Theta == 0 and is not an observed one, so it contributes exactly
 // fl(fl(1-0)+eps) = 1+eps.  Their total is removed before the loss is assembled (and before any
@@ -1070,6 +1118,42 @@ void timing_collect(nbmf_ctx* c) {
 double ll_pad_of(const nbmf_ctx* c) {
   const double n_pad = (double)c->mA * (double)c->nA - (double)c->m * (double)c->n;
   return (c->data_kind == DATA_BIN) ? n_pad * log(1.0 + c->eps) : 0.0;
+}
+
+// What travels after a sweep over image A (H-pass or Theta-only sweep), and where the global
+// log-likelihood ends up (c->ll_ptr):
+//   single GPU        nothing; finalize sums the per-wave partials itself
+//   axis 0 (rows)     H-pass: [P1 | P2 | loglik] in Pbuf; Theta-only sweep: the loglik scalar
+//   axis 1 (columns)  [loglik, prior A, prior B]: the products stay local, the scalars do not
+int enqueue_exchange_after_sweep(nbmf_ctx* c, const PassArgs& a, bool with_products, int strict) {
+  const int n_loss = c->chunksH * a.Cb;
+  const double pad = strict ? 0.0 : ll_pad_of(c);
+  if (!is_sharded(c)) {
+    c->ll_ptr = nullptr;
+    return NBMF_OK;
+  }
+  const long long per = (long long)c->KP * c->nA;
+  if (c->shard_axis == 0 && with_products) {
+    hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, a.out1, a.out2,
+                       c->lossbuf, c->Pbuf, c->chunksH, per, n_loss, pad, c->flags);
+    HIPCHK(hipGetLastError());
+    if (int rc = all_reduce_inplace(c, c->Pbuf, (size_t)(2 * per + 1))) return rc;
+    c->ll_ptr = c->Pbuf + 2 * per;
+    return NBMF_OK;
+  }
+  hipLaunchKernelGGL(ll_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->lossbuf, n_loss, pad, c->sbuf,
+                     c->flags);
+  HIPCHK(hipGetLastError());
+  size_t cnt = 1;
+  if (c->shard_axis == 1) {
+    hipLaunchKernelGGL(prior_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->prior, c->n_prior_blocks,
+                       c->sbuf + 1, c->flags);
+    HIPCHK(hipGetLastError());
+    cnt = 3;
+  }
+  if (int rc = all_reduce_inplace(c, c->sbuf, cnt)) return rc;
+  c->ll_ptr = c->sbuf;
+  return NBMF_OK;
 }
 
 int enqueue_h_pass(nbmf_ctx* c) {
@@ -1092,22 +1176,7 @@ int enqueue_h_pass(nbmf_ctx* c) {
     EvScope ev(c, 0);
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
   }
-  if (c->comm || c->host_reduce) {
-    const long long per = (long long)c->KP * c->nA;
-    hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, a.out1, a.out2,
-                       c->lossbuf, c->Pbuf, c->chunksH, per, c->chunksH * a.Cb, ll_pad_of(c), c->flags);
-    HIPCHK(hipGetLastError());
-    const size_t cnt = (size_t)(2 * per + 1);
-    if (c->comm) {
-      NCCLCHK(g_rccl.AllReduce(c->Pbuf, c->Pbuf, cnt, kNcclFloat64, kNcclSum, c->comm, c->stream));
-    } else {
-      HIPCHK(hipMemcpyAsync(c->host_buf, c->Pbuf, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      if (c->host_reduce(c->host_reduce_user, c->host_buf, (int64_t)cnt) != 0)
-        return fail(NBMF_ERR_COMM, "host all-reduce callback failed");
-      HIPCHK(hipMemcpyAsync(c->Pbuf, c->host_buf, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    }
-  }
+  if (int rc = enqueue_exchange_after_sweep(c, a, /*with_products=*/true, /*strict=*/0)) return rc;
   return NBMF_OK;
 }
 
@@ -1131,32 +1200,21 @@ int enqueue_loglik_pass(nbmf_ctx* c, int strict) {
   a.eps = c->eps;
   a.strict = strict;
   HIPCHK(launch_pass<MODE_L>(c->KB, c->data_kind, a, c->chunksH, c->stream));
-  if (c->comm || c->host_reduce) {
-    // sharded: only the scalar travels (same slot of Pbuf that the H-pass payload uses for it)
-    double* tail = c->Pbuf + 2 * (size_t)c->KP * c->nA;
-    hipLaunchKernelGGL(ll_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->lossbuf,
-                       c->chunksH * a.Cb, strict ? 0.0 : ll_pad_of(c), tail, c->flags);
-    HIPCHK(hipGetLastError());
-    if (c->comm) {
-      NCCLCHK(g_rccl.AllReduce(tail, tail, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
-    } else {
-      HIPCHK(hipMemcpyAsync(c->host_buf, tail, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      if (c->host_reduce(c->host_reduce_user, c->host_buf, 1) != 0)
-        return fail(NBMF_ERR_COMM, "host all-reduce callback failed");
-      HIPCHK(hipMemcpyAsync(tail, c->host_buf, sizeof(double), hipMemcpyHostToDevice, c->stream));
-    }
-  }
+  if (int rc = enqueue_exchange_after_sweep(c, a, /*with_products=*/false, strict)) return rc;
   return NBMF_OK;
 }
 
-int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false) {
-  const long long per = (long long)c->KP * c->nA;
-  const bool sharded = c->comm || c->host_reduce;
-  const double* ll_src = sharded ? c->Pbuf + 2 * per : c->lossbuf;
-  const int n_ll = sharded ? 1 : c->chunksH * (int)(c->nA / 16);
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, ll_src, n_ll, sharded ? 0.0 : ll_pad_of(c),
-                     c->prior, c->n_prior_blocks, loglik_only ? 0.0 : c->alpha - 1.0, loglik_only ? 0.0 : c->beta - 1.0,
+int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false, int strict = 0) {
+  // single GPU: per-wave partials + pad correction here; sharded: the exchanged scalar (pad already removed)
+  const bool sh = is_sharded(c) && c->ll_ptr;
+  const double* ll_src = sh ? c->ll_ptr : c->lossbuf;
+  const int n_ll = sh ? 1 : c->chunksH * (int)(c->nA / 16);
+  const double pad = (sh || strict) ? 0.0 : ll_pad_of(c);
+  // axis 1: the prior sums were exchanged with the log-likelihood
+  const bool prior_x = sh && c->shard_axis == 1;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, ll_src, n_ll, pad,
+                     prior_x ? (const double*)(c->sbuf + 1) : (const double*)c->prior, prior_x ? 1 : c->n_prior_blocks,
+                     loglik_only ? 0.0 : c->alpha - 1.0, loglik_only ? 0.0 : c->beta - 1.0,
                      loglik_only ? -1.0 : c->n_obs_global, c->losses_d, t, tol, c->scal, c->flags);
   HIPCHK(hipGetLastError());
   return NBMF_OK;
@@ -1164,11 +1222,11 @@ int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false) {
 
 int enqueue_h_update(nbmf_ctx* c) {
   const size_t per = (size_t)c->KP * c->nA;
-  const bool sharded = c->comm || c->host_reduce;
-  const double* s1 = sharded ? c->Pbuf : c->slabH;
-  const double* s2 = sharded ? c->Pbuf + per : c->slabH + (size_t)c->chunksH * per;
+  const bool reduced = is_sharded(c) && c->shard_axis == 0;     // products arrive all-reduced in Pbuf
+  const double* s1 = reduced ? c->Pbuf : c->slabH;
+  const double* s2 = reduced ? c->Pbuf + per : c->slabH + (size_t)c->chunksH * per;
   hipLaunchKernelGGL(h_update_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, s1, s2,
-                     sharded ? 1 : c->chunksH, c->Hn, c->HT, c->HG, c->prior, c->k, c->KP, (long long)c->n,
+                     reduced ? 1 : c->chunksH, c->Hn, c->HT, c->HG, c->prior, c->k, c->KP, (long long)c->n,
                      (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags);
   HIPCHK(hipGetLastError());
   return NBMF_OK;
@@ -1194,10 +1252,23 @@ int enqueue_w_step(nbmf_ctx* c, int projection) {
     EvScope ev(c, 1);
     HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, a, c->chunksW, c->stream));
   }
+  const double* q = c->slabW;
+  int chunks = c->chunksW;
+  double n_div = (double)c->n;
+  if (is_sharded(c) && c->shard_axis == 1) {
+    // columns of Y are split: the bracket of _solver.py:53 is a sum over ranks -> one all-reduce of K x m
+    const long long per = (long long)c->KP * c->mA;
+    hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream,
+                       (const double*)c->slabW, c->Qbuf, c->chunksW, per, c->flags);
+    HIPCHK(hipGetLastError());
+    if (int rc = all_reduce_inplace(c, c->Qbuf, (size_t)per)) return rc;
+    q = c->Qbuf;
+    chunks = 1;
+    n_div = c->n_div_global;
+  }
   hipLaunchKernelGGL(w_update_kernel, dim3((unsigned)(c->mA / WU_COLS)), dim3(WU_COLS * WU_GROUPS),
-                     sizeof(double) * ((size_t)c->KP + 2) * WU_COLS, c->stream, c->slabW,
-                     c->chunksW, c->Wn, c->WT, c->WG, c->k, c->KP, (long long)c->m, (long long)c->mA, (double)c->n,
-                     c->rowcnt, projection, c->flags);
+                     sizeof(double) * ((size_t)c->KP + 2) * WU_COLS, c->stream, q, chunks, c->Wn, c->WT, c->WG, c->k, c->KP,
+                     (long long)c->m, (long long)c->mA, n_div, c->rowcnt, projection, c->flags);
   HIPCHK(hipGetLastError());
   return NBMF_OK;
 }
@@ -1291,6 +1362,7 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
   c->n_prior_blocks = (int)(((size_t)c->KP * c->nA + 255) / 256);
   HIPCHK(hipMalloc(&c->prior, sizeof(double) * 2 * (size_t)c->n_prior_blocks));
   HIPCHK(hipMalloc(&c->scal, sizeof(double) * 8));
+  HIPCHK(hipMalloc(&c->sbuf, sizeof(double) * 8));
   HIPCHK(hipMalloc(&c->flags, sizeof(int) * 8));
   HIPCHK(hipMalloc(&c->stats, sizeof(unsigned long long) * 8));
   HIPCHK(hipMalloc(&c->rowcnt, sizeof(double) * (size_t)c->mA));
@@ -1309,7 +1381,8 @@ int nbmf_destroy(nbmf_ctx* c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   if (c->host_buf) hipHostFree(c->host_buf);
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
-                  c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats};
+                  c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
+                  c->sbuf, c->Qbuf};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (hipEvent_t e : c->ev) hipEventDestroy(e);
@@ -1608,13 +1681,7 @@ int nbmf_loglik_strict(nbmf_ctx* c, double* loglik) {
   if (int rc = ensure_losses(c, 1)) return rc;
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
   if (int rc = enqueue_loglik_pass(c, 1)) return rc;
-  // ordered sum of the per-wave partials; no pad correction (pad entries are not observed), no prior
-  const bool sharded = c->comm || c->host_reduce;
-  const double* ll_src = sharded ? c->Pbuf + 2 * (size_t)c->KP * c->nA : c->lossbuf;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, ll_src,
-                     sharded ? 1 : c->chunksH * (int)(c->nA / 16), 0.0, c->prior, c->n_prior_blocks, 0.0, 0.0, -1.0,
-                     c->losses_d, 0, 0.0, c->scal, c->flags);
-  HIPCHK(hipGetLastError());
+  if (int rc = enqueue_finalize(c, 0, 0.0, /*loglik_only=*/true, /*strict=*/1)) return rc;   // no pad term, no prior
   HIPCHK(hipMemcpyAsync(loglik, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return NBMF_OK;
@@ -1627,44 +1694,61 @@ int nbmf_comm_unique_id(void* id128) {
   return NBMF_OK;
 }
 
-int nbmf_comm_init(nbmf_ctx* c, const void* id128, int nranks, int rank) {
-  if (!c || !id128) return fail(NBMF_ERR_ARG, "null argument");
+// Shared tail of the two comm-init entry points: exchange buffers for the chosen axis and the global
+// quantities the update formulas need.
+static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
+  c->nranks = nranks;
+  c->rank = rank;
+  c->shard_axis = shard_axis;
+  if (shard_axis == 1 && !c->Qbuf) HIPCHK(hipMalloc(&c->Qbuf, sizeof(double) * (size_t)c->KP * c->mA));
+  // global observed count (the divisor of _solver.py:162) and, when the columns are split, the global
+  // column count (the "/ n" of :54) and the per-row observed counts of the Duchi extension
+  double h[2] = {c->n_obs, (double)c->n};
+  HIPCHK(hipMemcpyAsync(c->sbuf, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+  if (int rc = all_reduce_inplace(c, c->sbuf, 2)) return rc;
+  HIPCHK(hipMemcpyAsync(h, c->sbuf, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->n_obs_global = h[0];
+  c->n_div_global = (shard_axis == 1) ? h[1] : (double)c->n;
+  if (shard_axis == 1) {
+    HIPCHK(hipMemsetAsync(c->rowcnt + c->m, 0, sizeof(double) * (size_t)(c->mA - c->m), c->stream));
+    if (int rc = all_reduce_inplace(c, c->rowcnt, (size_t)c->mA)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return NBMF_OK;
+}
+
+static int comm_check_args(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(NBMF_ERR_ARG, "bad rank %d / nranks %d", rank, nranks);
-  if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "call nbmf_upload before nbmf_comm_init (the observed count is reduced here)");
+  if (shard_axis != 0 && shard_axis != 1) return fail(NBMF_ERR_ARG, "shard_axis must be 0 (rows of Y) or 1 (columns of Y)");
+  if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "call nbmf_upload before attaching a communicator (global counts are reduced there)");
+  if (c->comm || c->host_reduce) return fail(NBMF_ERR_STATE, "a communicator is already attached");
+  return NBMF_OK;
+}
+
+int nbmf_comm_init(nbmf_ctx* c, const void* id128, int nranks, int rank, int shard_axis) {
+  if (!c || !id128) return fail(NBMF_ERR_ARG, "null argument");
+  if (int rc = comm_check_args(c, nranks, rank, shard_axis)) return rc;
   if (int rc = set_device(c)) return rc;
   if (int rc = load_rccl()) return rc;
   Uid uid;
   memcpy(uid.internal, id128, 128);
   NCCLCHK(g_rccl.CommInitRank(&c->comm, nranks, uid, rank));
-  c->nranks = nranks;
-  c->rank = rank;
-  // global observed count (the divisor of _solver.py:162)
-  HIPCHK(hipMemcpyAsync(c->scal + 4, &c->n_obs, sizeof(double), hipMemcpyHostToDevice, c->stream));
-  NCCLCHK(g_rccl.AllReduce(c->scal + 4, c->scal + 4, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
-  HIPCHK(hipMemcpyAsync(&c->n_obs_global, c->scal + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return NBMF_OK;
+  return comm_finish_init(c, nranks, rank, shard_axis);
 }
 
-int nbmf_comm_init_host(nbmf_ctx* c, nbmf_host_allreduce_fn fn, void* user, int nranks, int rank) {
+int nbmf_comm_init_host(nbmf_ctx* c, nbmf_host_allreduce_fn fn, void* user, int nranks, int rank, int shard_axis) {
   if (!c || !fn) return fail(NBMF_ERR_ARG, "null argument");
-  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(NBMF_ERR_ARG, "bad rank %d / nranks %d", rank, nranks);
-  if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "call nbmf_upload before nbmf_comm_init_host (the observed count is reduced here)");
-  if (c->comm) return fail(NBMF_ERR_STATE, "an RCCL communicator is already attached");
+  if (int rc = comm_check_args(c, nranks, rank, shard_axis)) return rc;
   if (int rc = set_device(c)) return rc;
-  const size_t cnt = 2 * (size_t)c->KP * c->nA + 1;
+  const size_t cnt = std::max<size_t>(2 * (size_t)c->KP * c->nA + 1, (size_t)c->KP * c->mA);
   if (!c->host_buf) {
     HIPCHK(hipHostMalloc((void**)&c->host_buf, cnt * sizeof(double), hipHostMallocDefault));
     c->host_buf_count = cnt;
   }
   c->host_reduce = fn;
   c->host_reduce_user = user;
-  c->nranks = nranks;
-  c->rank = rank;
-  c->host_buf[0] = c->n_obs;
-  if (fn(user, c->host_buf, 1) != 0) return fail(NBMF_ERR_COMM, "host all-reduce callback failed");
-  c->n_obs_global = c->host_buf[0];
-  return NBMF_OK;
+  return comm_finish_init(c, nranks, rank, shard_axis);
 }
 
 int nbmf_timing_enable(nbmf_ctx* c, int enable) {

@@ -39,10 +39,16 @@ def _worker(rank, world, port, q):
         allreduce(nobs)
         Wl, Hn, losses = sharded_oracle.sharded_solve(Y[r0:r1], mask[r0:r1], W[:, r0:r1], H, 1.2, 1.3, nobs[0],
                                                       allreduce, max_iter=25)
+        # the other split (columns of Y): local H-step, all-reduced W-step bracket
+        c0, c1 = _dist.shard_bounds(N, world, rank)
+        nobs2 = np.array([float(np.count_nonzero(mask[:, c0:c1]))])
+        allreduce(nobs2)
+        Wc, Hc, lc = sharded_oracle.sharded_solve_cols(Y[:, c0:c1], mask[:, c0:c1], W, H[:, c0:c1], 1.2, 1.3, nobs2[0], N,
+                                                       allreduce, max_iter=25)
         # rendezvous object broadcast as attach_comm does it
         uid = [bytes(range(128)) if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        q.put((rank, r0, r1, Wl, Hn, losses, uid[0]))
+        q.put((rank, r0, r1, Wl, Hn, losses, uid[0], (c0, c1, Wc, Hc, lc)))
     finally:
         dist.destroy_process_group()
 
@@ -73,6 +79,14 @@ def test_sharded_iteration_equals_unsharded():
         np.testing.assert_allclose(r[5], lr, rtol=1e-12, atol=0)
         assert r[6] == bytes(range(128))
     np.testing.assert_array_equal(res[0][4], res[1][4])                # bitwise identical across ranks
+    # column split
+    assert [r[7][:2] for r in res] == [(0, 60), (60, 120)]
+    Hc = np.concatenate([r[7][3] for r in res], axis=1)
+    np.testing.assert_allclose(Hc, Hr, rtol=0, atol=1e-12)
+    for r in res:
+        np.testing.assert_allclose(r[7][2].T, Wr, rtol=0, atol=1e-12)  # W replicated
+        np.testing.assert_allclose(r[7][4], lr, rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(res[0][7][2], res[1][7][2])
 
 
 def test_shard_bounds_cover_and_balance():

@@ -37,7 +37,7 @@ def _worker_dirbeta_restarts(rank, world, port, q):
         M, N, K, Y, mask = _problem()
         V, Vmask = Y[:300, :], mask[:300, :]                 # dir-beta on a 300 x 333 matrix, column shards
         c0, c1 = _dist.shard_bounds(V.shape[1], world, rank)
-        W, Hl, losses, n_iter = _dist.fit_sharded(V[:, c0:c1], V.shape, c0, 9, dist, orientation="dir-beta",
+        W, Hl, losses, n_iter = _dist.fit_sharded(V[:, c0:c1], V.shape, c0, 9, dist, orientation="dir-beta", shard="cols",
                                                   max_iter=25, tol=0, mask_local=Vmask[:, c0:c1], random_state=4,
                                                   device=0, transport="host")
         best = _dist.fit_restarts(V, 9, dist, n_init=3, random_state=10, device=0, max_iter=15, tol=0, mask=Vmask)
@@ -108,6 +108,15 @@ def test_two_ranks_stop_rule_agrees():
         losses, n_iter = ctx.run(400, 1e-4)
     assert n_iter == n1
     np.testing.assert_array_equal(losses, np.array(l1))
+    # same through the column-split code path (W-step exchange + scalar exchange), one rank
+    with _hip.Context(M, N, K) as ctx:
+        ctx.set_hyper(1.2, 1.2)
+        ctx.upload(Y, mask=mask)
+        ctx.set_factors(W, H)
+        ctx.comm_init(_hip.comm_unique_id(), 1, 0, shard_axis=1)
+        losses, n_iter = ctx.run(10, 0.0)
+        assert ctx.loss() == losses[-1]
+    np.testing.assert_array_equal(losses, np.array(l1))
 
 
 def test_rccl_single_rank():
@@ -158,3 +167,63 @@ def test_dir_beta_column_shards_and_parallel_restarts():
         assert ib == k and nb == 15
         np.testing.assert_array_equal(Wb, seq[k][0])
         np.testing.assert_array_equal(lb, seq[k][2])
+
+
+def _worker_axis1(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    from nbmf_mm_amd import _dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        M, N, K, Y, mask = _problem()
+        V, Vmask = Y[:300, :], mask[:300, :]
+        out = {}
+        # dir-beta with V split by ROWS (the all-reduce moves to the W-step)
+        r0, r1 = _dist.shard_bounds(V.shape[0], world, rank)
+        out["db_rows"] = (r0, r1) + _dist.fit_sharded(V[r0:r1], V.shape, r0, 9, dist, orientation="dir-beta", shard="rows",
+                                                     max_iter=25, tol=0, mask_local=Vmask[r0:r1], random_state=4,
+                                                     device=0, transport="host")
+        # beta-dir with V split by COLUMNS, Duchi projection (needs the global per-row observed counts), stop rule on
+        c0, c1 = _dist.shard_bounds(V.shape[1], world, rank)
+        out["bd_cols"] = (c0, c1) + _dist.fit_sharded(V[:, c0:c1], V.shape, c0, 9, dist, orientation="beta-dir", shard="cols",
+                                                     max_iter=200, tol=1e-4, mask_local=Vmask[:, c0:c1], random_state=4,
+                                                     projection="duchi", device=0, transport="host")
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_column_split_of_the_internal_matrix():
+    import torch.multiprocessing as mp
+    from nbmf_mm_amd import nbmf_mm_solver
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_axis1, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [o for _, o in sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    M, N, K, Y, mask = _problem()
+    V, Vmask = Y[:300, :], mask[:300, :]
+    # dir-beta / rows: W (Beta factor, M x k) comes back in row slices, H (k x N, simplex columns) whole
+    W1, H1, l1, _, _ = nbmf_mm_solver(V, 9, max_iter=25, tol=0, mask=Vmask, random_state=4, orientation="dir-beta")
+    W = np.concatenate([r["db_rows"][2] for r in res], axis=0)
+    np.testing.assert_allclose(W, W1, rtol=0, atol=1e-12)
+    for r in res:
+        np.testing.assert_allclose(r["db_rows"][3], H1, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(r["db_rows"][4], l1, rtol=1e-10, atol=0)
+    np.testing.assert_array_equal(res[0]["db_rows"][3], res[1]["db_rows"][3])      # replicated factor bitwise equal
+    # beta-dir / cols with Duchi and the stop rule
+    W2, H2, l2, _, n2 = nbmf_mm_solver(V, 9, max_iter=200, tol=1e-4, mask=Vmask, random_state=4, projection="duchi")
+    assert 3 < n2 < 200
+    Hc = np.concatenate([r["bd_cols"][3] for r in res], axis=1)
+    np.testing.assert_allclose(Hc, H2, rtol=0, atol=1e-11)
+    for r in res:
+        assert r["bd_cols"][5] == n2
+        np.testing.assert_allclose(r["bd_cols"][2], W2, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(r["bd_cols"][4], l2, rtol=1e-10, atol=0)
