@@ -73,6 +73,20 @@ def cpu_baseline(N, K, seed, masked, budget_rows=2048, iters=3):
     return dt, threads, float(loss)
 
 
+def profiled_traffic(M, N, K, masked, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/r1_c3_k64_masked.json <- tools/prof_summary.py): (2*FETCH_SIZE + WRITE_SIZE) KiB,
+    the x2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  Only for the
+    default workload on one GPU; otherwise None."""
+    path = os.path.join(ROOT, "profiles", "r1_c3_k64_masked.json")
+    if (M, N, K, masked, world) != (65536, 8192, 64, True, 1) or not os.path.exists(path):
+        return None, None
+    rec = json.load(open(path))
+    if "FETCH_SIZE" not in rec or "WRITE_SIZE" not in rec:
+        return None, None
+    return (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0, "profiles/r1_c3_k64_masked.json"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +177,7 @@ def main():
         # algorithmic flop of one H-pass launch: Theta + two back-products = 6*m*N*K
         flop_pass = 6.0 * m_loc * N * K
         achieved = flop_pass / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
+        traffic, traffic_src = profiled_traffic(M, N, K, masked, world)
         out = {
             "metric": "MM-iterations/sec", "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
@@ -176,7 +191,9 @@ def main():
                        "sharding": f"rows/{world} ({transport} all-reduce of 2*K*N+1 doubles per iteration)" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_unit": "bytes per launch (PMC: (2*FETCH_SIZE + WRITE_SIZE) KiB; algorithmic: "
+                                         "m*N code bytes + 2*chunks*K*N*8 slab bytes = %.3g)" % (m_loc * N + 2.0 * 16 * K * N * 8),
                          "hpass_ms": h_ms, "wpass_ms": w_ms,
                          "iteration_frac": (12.0 * m_loc * N * K * its / 1e12) / PEAK_FP64_MFMA_TFLOPS},
             "upload": {"seconds": t_up, "GBps_pcie_inclusive": bytes_up / t_up / 1e9},

@@ -69,3 +69,20 @@ def test_argument_errors_surface_without_a_gpu():
     assert b"n_components" in lib.nbmf_last_error()
     assert lib.nbmf_run(None, 1, 0.0, None, None) == _hip.NBMF_ERR_ARG
     assert lib.nbmf_destroy(None) == 0
+
+
+def test_header_compiles_as_c99_and_links():
+    """include/nbmf_hip.h is a C header: the C consumer builds against it and the library with gcc."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = os.path.join(ROOT, "build", "abi_smoke_cpu")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-L", os.path.join(ROOT, "nbmf_mm_amd"),
+                           "-lnbmf_hip", "-Wl,-rpath," + os.path.join(ROOT, "nbmf_mm_amd"), "-lm", "-o", exe])
+    from nbmf_mm_amd import _hip
+    if _hip.device_count() == 0:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 3 and "no GPU" in out.stderr      # fails loudly without a device

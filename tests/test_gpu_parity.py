@@ -428,3 +428,19 @@ def test_last_loss_sweep_is_bitwise_the_fused_one(hip):
             ctx.set_factors(W0, H0)
             b, _ = ctx.run(6, 0.0)
         np.testing.assert_array_equal(a, b[:5])
+
+
+def test_plain_c_consumer_of_the_abi(hip):
+    """tests/c/abi_smoke.c: a C99 program (no Python, no C++) driving libnbmf_hip.so end to end."""
+    import os, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    exe = os.path.join(root, "build", "abi_smoke_test")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "abi_smoke.c"), "-L", os.path.join(root, "nbmf_mm_amd"),
+                           "-lnbmf_hip", "-Wl,-rpath," + os.path.join(root, "nbmf_mm_amd"), "-lm", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_smoke ok" in out.stdout

@@ -41,5 +41,28 @@ def main(root):
                 print("%-40s n=%-3d dur_ns=%-10.0f %s" % (k, len(dur[k]) // max(1, len(agg[k])), sum(dur[k]) / len(dur[k]), " ".join(parts)))
 
 
+def sidecar(root, out_json):
+    """Machine-readable extract for bench.py's roofline.traffic: per-launch means of the dominant kernel."""
+    import json
+    rec = {}
+    for d in sorted(glob.glob(f"{root}/pmc_*")):
+        for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
+            acc = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if k.startswith("pass_kernel") and k.endswith(",H>"):
+                    acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    rec["kernel"] = k
+            for c, v in acc.items():
+                rec[c] = sum(v) / len(v)
+    for f in glob.glob(f"{root}/stats/*/*_kernel_stats.csv"):
+        for r in csv.DictReader(open(f)):
+            if short(r["Name"]) == rec.get("kernel"):
+                rec["avg_ns"] = float(r["AverageNs"])
+    json.dump(rec, open(out_json, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     main(sys.argv[1].rstrip("/"))
+    if len(sys.argv) > 2:
+        sidecar(sys.argv[1].rstrip("/"), sys.argv[2])
