@@ -34,6 +34,13 @@
 
 #include "../../include/nbmf_hip.h"
 
+#ifndef NBMF_STAGE_HALF
+#define NBMF_STAGE_HALF 1   // 16 KiB stages (3 workgroups per CU at K <= 64); 0 = 32 KiB stages
+#endif
+#ifndef NBMF_LDS_DMA
+#define NBMF_LDS_DMA 1   // stage the factor panels with global_load_lds (LDS-DMA); 0 = through registers
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -157,10 +164,14 @@ struct PassArgs {
 };
 
 template <int KB, int DATA, int MODE>
-__global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pass_kernel(PassArgs a) {
+__global__ __launch_bounds__(256, (NBMF_STAGE_HALF && KB <= 4) ? 3 : ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pass_kernel(PassArgs a) {
   constexpr int K = 16 * KB;
   constexpr int S = K / 4;            // Theta k-steps
+#if NBMF_STAGE_HALF
+  constexpr int NB = (KB >= 4) ? 1 : 4 / KB;   // experiment: 16 KiB stages -> 3 workgroups per CU
+#else
   constexpr int NB = 8 / KB;          // row blocks per LDS stage (32 KiB)
+#endif
   constexpr int BLK = K * 16;         // doubles per block per operand image
   constexpr bool U8 = (NB * BLK / 2) / 256 == 8;   // 16-byte pieces per thread per image: 4, or 8 at K = 128
   constexpr int STAGE_D = 2 * NB * BLK;   // doubles per stage: [NB][T image] then [NB][G image] (= 32 KB)
@@ -253,9 +264,34 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
     }                                                                           \
   }
 
+#if NBMF_LDS_DMA
+  // Experimental alternative staging: LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no VGPRs).
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef const __attribute__((address_space(1))) char glb_char;
+#define STAGE_DMA(RB, BUF)                                                                         \
+  {                                                                                                \
+    glb_char* gT_ = (glb_char*)(a.LT + (size_t)(RB) * BLK) + lane * 16;                           \
+    glb_char* gG_ = (glb_char*)(a.LG + (size_t)(RB) * BLK) + lane * 16;                           \
+    lds_char* l_ = (lds_char*)(lds + (BUF) * STAGE_D);                                             \
+    constexpr int PIECES_ = N2 * 16 / 1024; /* 1 KiB pieces per image */                           \
+    _Pragma("unroll") for (int u_ = 0; u_ < PIECES_ / 4; ++u_) {                                   \
+      const int piece_ = wave + 4 * u_;                                                            \
+      __builtin_amdgcn_global_load_lds(gT_ + piece_ * 1024, l_ + piece_ * 1024, 16, 0, 0);        \
+      __builtin_amdgcn_global_load_lds(gG_ + piece_ * 1024, l_ + N2 * 16 + piece_ * 1024, 16, 0, 0); \
+    }                                                                                              \
+    if (DATA == DATA_BIN) {                                                                        \
+      _Pragma("unroll") for (int b_ = 0; b_ < NB; ++b_) cnext[b_] = codes[(size_t)((RB) + b_) * 64]; \
+    }                                                                                              \
+  }
+#endif
+
   uint32_t ccur[NB];
+#if NBMF_LDS_DMA
+  STAGE_DMA(rb0, 0);
+#else
   STAGE_LOAD(rb0);
   STAGE_STORE(0);
+#endif
 #pragma unroll
   for (int b = 0; b < NB; ++b) ccur[b] = cnext[b];
   __syncthreads();
@@ -264,7 +300,11 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
   for (int rb = rb0; rb < rb1; rb += NB) {
     // issue next stage's global loads now; they land while this stage computes (clamped: the last
     // stage re-reads an in-range block, harmlessly)
+#if NBMF_LDS_DMA
+    STAGE_DMA(min(rb + NB, a.Rb - NB), buf ^ 1);   // nobody reads buf^1 between the last barrier and the next
+#else
     STAGE_LOAD(min(rb + NB, a.Rb - NB));
+#endif
     __builtin_amdgcn_sched_barrier(0);   // keep the loads here: hipcc otherwise sinks each one next to its ds_write
     const double* base = lds + buf * STAGE_D;
 
@@ -434,7 +474,9 @@ __global__ __launch_bounds__(256, ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pa
 
     // write the prefetched stage into the other buffer; its last readers finished before the previous
     // barrier, and this stage's readers use `buf`
+#if !NBMF_LDS_DMA
     STAGE_STORE(buf ^ 1);
+#endif
 #pragma unroll
     for (int b = 0; b < NB; ++b) ccur[b] = cnext[b];
     __syncthreads();
@@ -1011,7 +1053,7 @@ constexpr int kNcclSum = 0;       // ncclSum
 template <int KB, int DATA, int MODE>
 hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
   dim3 grid(a.Cb / WG_WAVES, chunks);
-  constexpr int lds_bytes = 2 * STAGE_BYTES;
+  constexpr int lds_bytes = (NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES;
   if (lds_bytes > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
