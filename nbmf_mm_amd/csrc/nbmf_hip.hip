@@ -34,6 +34,9 @@
 
 #include "../../include/nbmf_hip.h"
 
+#ifndef NBMF_DUAL_THETA
+#define NBMF_DUAL_THETA 1   // two interleaved Theta accumulation chains where a wave has its SIMD to itself
+#endif
 #ifndef NBMF_STAGE_HALF
 #define NBMF_STAGE_HALF 1   // 16 KiB stages (3 workgroups per CU at K <= 64); 0 = 32 KiB stages
 #endif
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(256, (NBMF_STAGE_HALF && KB <= 4) ? 3 : ((KB <= 4 |
       // ---- Theta tile: rows 16(rb+b)+4r+q, column 16cb+c in register r of lane (q,c).
       // (two interleaved accumulation chains: a dependent f64 MFMA issues ~10 % slower than an
       //  independent one when the SIMD's other wave is not there to fill the gap)
+      constexpr bool DUAL = NBMF_DUAL_THETA && (KB == 8 && MODE == MODE_H);   // only where one wave owns the SIMD
       d4 th = {0, 0, 0, 0}, th2 = {0, 0, 0, 0};
 #pragma unroll
       for (int g = 0; g < NGT; ++g) {
@@ -339,14 +343,17 @@ __global__ __launch_bounds__(256, (NBMF_STAGE_HALF && KB <= 4) ? 3 : ((KB <= 4 |
 #pragma unroll
         for (int i = 0; i < GT; i += 2) {
           th = __builtin_amdgcn_mfma_f64_16x16x4f64(tcur[i], rf[g * GT + i], th, 0, 0, 0);
-          th2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tcur[i + 1], rf[g * GT + i + 1], th2, 0, 0, 0);
+          if (DUAL)
+            th2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tcur[i + 1], rf[g * GT + i + 1], th2, 0, 0, 0);
+          else
+            th = __builtin_amdgcn_mfma_f64_16x16x4f64(tcur[i + 1], rf[g * GT + i + 1], th, 0, 0, 0);
         }
         if (g + 1 < NGT) {
 #pragma unroll
           for (int i = 0; i < GT; ++i) tcur[i] = tnxt[i];
         }
       }
-      th += th2;
+      if (DUAL) th += th2;
 
       // first back-product operand group: issued now, lands during the ratio arithmetic
       double gcur[GB];
@@ -674,6 +681,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
                                                        double tol, double* __restrict__ scal, int* __restrict__ flags) {
   __shared__ double sh[3][4];
   if (flags[0]) return;
+  if (t < 0) {
+    // replayed (hipGraph) form: the loss index lives on the device; the very first call of a run only
+    // arms the counter (the H-pass of iteration 0 has no finished iteration to score)
+    const int armed = flags[3];
+    __syncthreads();
+    if (!armed) {
+      if (threadIdx.x == 0) flags[3] = 1;
+      return;
+    }
+    t = flags[2];
+  }
   // three ordered sums in one sweep (same per-thread / butterfly / wave order as ordered_sum256, so the
   // single-GPU and the all-reduced paths agree bit for bit); the loads of the three streams overlap
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -703,6 +721,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
     const double loss = -(ll + A + B) / n_obs;   // :162
     losses[t] = loss;
     flags[1] = t + 1;
+    flags[2] = t + 1;
     if (t > 0) {
       const double prev = scal[0];
       if (fabs(prev - loss) / fabs(prev) < tol) flags[0] = 1;   // :169-174
@@ -1641,9 +1660,40 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   const int batch = (tol > 0.0) ? 8 : max_iter;
   int host_done = 0;
   int it = 0;
+  // One iteration = five launches with identical arguments every time (the loss index is counted on the
+  // device), so on a single GPU it can be captured once into a hipGraph and replayed.  Measured: no gain
+  // (config 1, 100x500 K=6: 14.7k it/s replayed vs 16.5k it/s eager) -- tiny problems are bound by the
+  // latency of the five dependent kernels, not by the host's launch rate -- so it is opt-in
+  // (NBMF_USE_GRAPH=1), never used with a communicator or event timing.
+  const bool use_graph = getenv("NBMF_USE_GRAPH") && !is_sharded(c) && !c->timing && max_iter >= 8;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  if (use_graph) {
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_h_pass(c);
+    if (!rc) rc = enqueue_finalize(c, -1, tol);
+    if (!rc) rc = enqueue_h_update(c);
+    if (!rc) rc = enqueue_w_step(c, c->projection);
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(NBMF_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+  }
+  struct GraphGuard {
+    hipGraph_t g;
+    hipGraphExec_t x;
+    ~GraphGuard() {
+      if (x) hipGraphExecDestroy(x);
+      if (g) hipGraphDestroy(g);
+    }
+  } guard{graph, gexec};
   while (it < max_iter && !host_done) {
     const int end = std::min(max_iter, it + batch);
     for (; it < end; ++it) {
+      if (use_graph) {
+        HIPCHK(hipGraphLaunch(gexec, c->stream));
+        continue;
+      }
       if (int rc = enqueue_h_pass(c)) return rc;
       if (it > 0)
         if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;
@@ -1660,7 +1710,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   }
   if (!host_done) {
     if (int rc = enqueue_loglik_pass(c, 0)) return rc;            // loss of the last iteration (Theta-only sweep)
-    if (int rc = enqueue_finalize(c, max_iter - 1, tol)) return rc;
+    if (int rc = enqueue_finalize(c, use_graph ? -1 : max_iter - 1, tol)) return rc;
   }
   int fl[2];
   HIPCHK(hipMemcpyAsync(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
