@@ -444,3 +444,22 @@ def test_plain_c_consumer_of_the_abi(hip):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi_smoke ok" in out.stdout
+
+
+def test_graph_replay_matches_eager(hip, monkeypatch):
+    """Opt-in hipGraph replay of the iteration (device-side loss index): same bits, same stop iteration."""
+    from nbmf_mm_amd import nbmf_mm_solver
+    X, M = midsize_XM()
+    X, M = X[:200, :333], M[:200, :333]
+    monkeypatch.delenv("NBMF_USE_GRAPH", raising=False)
+    W0, H0, l0, _, n0 = nbmf_mm_solver(X, 12, max_iter=300, tol=1e-4, random_state=3, mask=M)
+    Wf, Hf, lf, _, nf = nbmf_mm_solver(X, 12, max_iter=40, tol=0, random_state=3, mask=M)
+    monkeypatch.setenv("NBMF_USE_GRAPH", "1")
+    W1, H1, l1, _, n1 = nbmf_mm_solver(X, 12, max_iter=300, tol=1e-4, random_state=3, mask=M)
+    Wg, Hg, lg, _, ng = nbmf_mm_solver(X, 12, max_iter=40, tol=0, random_state=3, mask=M)
+    assert 8 < n0 < 300 and n1 == n0 and ng == nf == 40
+    np.testing.assert_array_equal(l1, l0)
+    np.testing.assert_array_equal(W1, W0)
+    np.testing.assert_array_equal(H1, H0)
+    np.testing.assert_array_equal(lg, lf)
+    np.testing.assert_array_equal(Wg, Wf)
