@@ -463,3 +463,38 @@ def test_graph_replay_matches_eager(hip, monkeypatch):
     np.testing.assert_array_equal(H1, H0)
     np.testing.assert_array_equal(lg, lf)
     np.testing.assert_array_equal(Wg, Wf)
+
+
+def test_storage_path_is_decided_by_the_whole_matrix(hip):
+    """The host samples a few rows to guess the storage path; the device pack checks every entry and the
+    upload falls back to the 8-byte path when the guess was wrong (data or mask)."""
+    r = np.random.default_rng(17)
+    Y = (r.random((100, 50)) < 0.3).astype(np.float64)
+    mask = (r.random((100, 50)) < 0.8).astype(np.float64)
+    W = r.uniform(0.1, 0.9, (4, 100)); W /= W.sum(axis=0, keepdims=True)
+    H = r.uniform(0.1, 0.9, (4, 50))
+    for Yv, mv, want_bin in [(Y, mask, True), (Y, None, True), (Y, mask.astype(bool), True)]:
+        with hip.Context(100, 50, 4) as ctx:
+            assert ctx.upload(Yv, mask=mv) is want_bin
+    Y2 = Y.copy(); Y2[37, 3] = 0.5                       # one non-binary entry in a row the sample skips
+    m2 = mask.copy(); m2[41, 7] = 0.25                   # one weight in the mask
+    for Yv, mv in [(Y2, mask), (Y, m2), (Y2, None)]:
+        with hip.Context(100, 50, 4) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            assert ctx.upload(Yv, mask=mv) is False
+            ctx.set_factors(W, H)
+            losses, _ = ctx.run(3, 0.0)
+            Wn, Hn = ctx.get_factors()
+        Wr, Hr = W, H
+        for _ in range(3):
+            Wr, Hr = orc.mm_step(Yv, Wr, Hr, mv, 1.2, 1.2)
+        np.testing.assert_allclose(Wn, Wr, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(Hn, Hr, rtol=0, atol=1e-13)
+        assert abs(losses[-1] - orc.mm_loss(Yv, Wr, Hr, mv, 1.2, 1.2)) <= 1e-12
+    # re-upload on the same context switches paths cleanly
+    with hip.Context(100, 50, 4) as ctx:
+        assert ctx.upload(Y2, mask=mask) is False
+        assert ctx.upload(Y, mask=mask) is True
+        ctx.set_factors(W, H)
+        a = ctx.loss()
+    assert abs(a - orc.mm_loss(Y, W, H, mask, 1.2, 1.2)) <= 1e-12
