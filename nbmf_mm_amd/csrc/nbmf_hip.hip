@@ -156,7 +156,7 @@ struct PassArgs {
   const double* RfT;    // [Cb][K/4][64]
   double* out1;         // [chunks][K][C_alloc]
   double* out2;         // MODE_H only
-  double* lossbuf;      // MODE_H: [chunks][Cb] per-wave log-likelihood partials
+  double* lossbuf;      // MODE_H/L: [chunks][Cb/4] per-workgroup log-likelihood partials
   const int* done;      // device stop flag: skip all work when set
   int Rb;               // row blocks of D (multiple of 8)
   int Cb;               // column strips of D (multiple of 4)
@@ -522,7 +522,12 @@ __global__ __launch_bounds__(256, (NBMF_STAGE_HALF && KB <= 4) ? 3 : ((KB <= 4 |
     else
       ll = llsum;
     ll = wave_sum(ll);
-    if (lane == 0) a.lossbuf[(size_t)chunk * a.Cb + cb] = ll;
+    // one partial per workgroup: the four waves in wave order (fixed -> reproducible)
+    __syncthreads();                       // all waves are done with the staging buffers
+    if (lane == 0) lds[wave] = ll;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      a.lossbuf[(size_t)chunk * gridDim.x + blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
   }
 }
 
@@ -696,6 +701,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
   // single-GPU and the all-reduced paths agree bit for bit); the loads of the three streams overlap
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   const int n_max = n_ll > n_prior ? n_ll : n_prior;
+#pragma unroll 4
   for (int j = threadIdx.x; j < n_max; j += 256) {
     if (j < n_ll) s0 += ll_src[j];
     if (j < n_prior) {
@@ -1187,7 +1193,7 @@ double ll_pad_of(const nbmf_ctx* c) {
 //   axis 0 (rows)     H-pass: [P1 | P2 | loglik] in Pbuf; Theta-only sweep: the loglik scalar
 //   axis 1 (columns)  [loglik, prior A, prior B]: the products stay local, the scalars do not
 int enqueue_exchange_after_sweep(nbmf_ctx* c, const PassArgs& a, bool with_products, int strict) {
-  const int n_loss = c->chunksH * a.Cb;
+  const int n_loss = c->chunksH * (a.Cb / WG_WAVES);   // one log-likelihood partial per workgroup
   const double pad = strict ? 0.0 : ll_pad_of(c);
   if (!is_sharded(c)) {
     c->ll_ptr = nullptr;
@@ -1269,7 +1275,7 @@ int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false, i
   // single GPU: per-wave partials + pad correction here; sharded: the exchanged scalar (pad already removed)
   const bool sh = is_sharded(c) && c->ll_ptr;
   const double* ll_src = sh ? c->ll_ptr : c->lossbuf;
-  const int n_ll = sh ? 1 : c->chunksH * (int)(c->nA / 16);
+  const int n_ll = sh ? 1 : c->chunksH * (int)(c->nA / 16 / WG_WAVES);
   const double pad = (sh || strict) ? 0.0 : ll_pad_of(c);
   // axis 1: the prior sums were exchanged with the log-likelihood
   const bool prior_x = sh && c->shard_axis == 1;

@@ -12,7 +12,7 @@ def short(name):
     m = re.search(r"pass_kernel<(\d+), (\d+), (\d+)>", name)
     if m:
         kb, data, mode = map(int, m.groups())
-        return f"pass_kernel<K={16*kb},{['BIN','F64','F64M'][data]},{'H' if mode == 0 else 'W'}>"
+        return f"pass_kernel<K={16*kb},{['BIN','F64','F64M'][data]},{'HWL'[mode]}>"
     m = re.search(r"(\w+_kernel|__amd_rocclr_\w+)", name)
     return m.group(1) if m else name[:40]
 
