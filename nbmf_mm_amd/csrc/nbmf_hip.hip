@@ -1108,17 +1108,52 @@ hipError_t launch_pass(int KB, int data_kind, const PassArgs& a, int chunks, hip
   return hipErrorInvalidValue;
 }
 
-void pick_chunks(int strips_groups, int Rb, int NB, int* chunks, int* CH) {
-  // aim for >= ~2048 workgroups (256 CUs x 2 resident x 4 rounds) without making chunks tiny
-  // (NBMF_TARGET_WGS overrides the target: tuning experiments only)
+template <int DATA, int MODE>
+const void* pass_ptr_kb(int KB) {
+  switch (KB) {
+    case 1: return (const void*)pass_kernel<1, DATA, MODE>;
+    case 2: return (const void*)pass_kernel<2, DATA, MODE>;
+    case 4: return (const void*)pass_kernel<4, DATA, MODE>;
+    case 8: return (const void*)pass_kernel<8, DATA, MODE>;
+  }
+  return nullptr;
+}
+
+template <int MODE>
+const void* pass_ptr(int KB, int data_kind) {
+  switch (data_kind) {
+    case DATA_BIN: return pass_ptr_kb<DATA_BIN, MODE>(KB);
+    case DATA_F64: return pass_ptr_kb<DATA_F64, MODE>(KB);
+    case DATA_F64M: return pass_ptr_kb<DATA_F64M, MODE>(KB);
+  }
+  return nullptr;
+}
+
+// workgroups of this pass kernel that one CU holds at once (registers and LDS decide)
+template <int MODE>
+int resident_per_cu(int KB, int data_kind) {
+  int n = 0;
+  const void* f = pass_ptr<MODE>(KB, data_kind);
+  const int lds_bytes = (NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES;
+  if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, lds_bytes) != hipSuccess || n < 1) n = 2;
+  return std::min(n, 8);
+}
+
+// Split a sweep of Rb row blocks into chunks: aim for ~2048 workgroups (several rounds over the 512-768
+// resident ones, so the dispatcher can even out slow workgroups) without making the sweeps shorter than
+// 64 blocks (each workgroup pays a fixed prologue/epilogue and writes its own partial slab).
+// Measured at c3 / K=64: 768 workgroups = exactly one round of the 768 resident slots is SLOWER (3.23 ms)
+// than 2048 (3.15 ms); anything from 1536 to 4608 is within 1 %.  `slots` is kept for diagnostics.
+// NBMF_TARGET_WGS=<n> overrides the target (tuning experiments only).
+void pick_chunks(int strips_groups, int Rb, int NB, int slots, int* chunks, int* CH) {
+  (void)slots;
   int target = 2048;
   if (const char* e = getenv("NBMF_TARGET_WGS")) target = std::max(1, atoi(e));
   int want = (target + strips_groups - 1) / strips_groups;
-  int max_chunks = Rb / NB;
-  if (want > max_chunks) want = max_chunks;
-  if (want < 1) want = 1;
+  const int max_chunks = std::max(1, Rb / NB);
+  want = std::min(std::max(want, 1), max_chunks);
   int ch = (Rb + want - 1) / want;
-  ch = std::max(ch, std::min(Rb, 64));   // short sweeps pay the per-workgroup prologue/epilogue and slab traffic
+  ch = std::max(ch, std::min(Rb, 64));
   ch = (int)round_up(ch, NB);
   *CH = ch;
   *chunks = (Rb + ch - 1) / ch;
@@ -1349,6 +1384,31 @@ int ensure_losses(nbmf_ctx* c, int cap) {
   return NBMF_OK;
 }
 
+// Chunking of the two sweeps and the slabs that go with it; needs the storage path (it decides the
+// kernels' residency), so it runs at the end of nbmf_upload.
+int setup_workspaces(nbmf_ctx* c) {
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, c->device));
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const int NB = 8 / c->KB;
+  const int slotsH = cus * resident_per_cu<MODE_H>(c->KB, c->data_kind);
+  const int slotsW = cus * resident_per_cu<MODE_W>(c->KB, c->data_kind);
+  pick_chunks((int)(c->nA / 16 / WG_WAVES), (int)(c->mA / 16), NB, slotsH, &c->chunksH, &c->CH_H);
+  pick_chunks((int)(c->mA / 16 / WG_WAVES), (int)(c->nA / 16), NB, slotsW, &c->chunksW, &c->CH_W);
+  if (getenv("NBMF_DEBUG"))
+    fprintf(stderr, "[nbmf] K_pad=%d path=%d: H-pass %d x %d workgroups (chunk %d blocks, %d slots), W-pass %d x %d (chunk %d, %d slots)\n",
+            c->KP, c->data_kind, (int)(c->nA / 64), c->chunksH, c->CH_H, slotsH, (int)(c->mA / 64), c->chunksW, c->CH_W, slotsW);
+  for (double** p : {&c->slabH, &c->slabW, &c->lossbuf}) {
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+  }
+  const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
+  HIPCHK(hipMalloc(&c->slabH, 2 * (size_t)c->chunksH * fh));
+  HIPCHK(hipMalloc(&c->slabW, (size_t)c->chunksW * fw));
+  HIPCHK(hipMalloc(&c->lossbuf, sizeof(double) * (size_t)c->chunksH * (c->nA / 16 / WG_WAVES)));
+  return NBMF_OK;
+}
+
 int ready(nbmf_ctx* c) {
   if (!c) return fail(NBMF_ERR_ARG, "null context");
   if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "nbmf_upload has not been called");
@@ -1419,13 +1479,8 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
   HIPCHK(hipMalloc(&c->Hn, fh));
   HIPCHK(hipMalloc(&c->HT, fh));
   HIPCHK(hipMalloc(&c->HG, fh));
-  const int NB = 8 / c->KB;
-  pick_chunks((int)(c->nA / 16 / WG_WAVES), (int)(c->mA / 16), NB, &c->chunksH, &c->CH_H);
-  pick_chunks((int)(c->mA / 16 / WG_WAVES), (int)(c->nA / 16), NB, &c->chunksW, &c->CH_W);
-  HIPCHK(hipMalloc(&c->slabH, 2 * (size_t)c->chunksH * fh));
-  HIPCHK(hipMalloc(&c->slabW, (size_t)c->chunksW * fw));
+  // (the pass workspaces depend on the storage path: setup_workspaces, called by nbmf_upload)
   HIPCHK(hipMalloc(&c->Pbuf, 2 * fh + 64));
-  HIPCHK(hipMalloc(&c->lossbuf, sizeof(double) * (size_t)c->chunksH * (c->nA / 16)));
   c->n_prior_blocks = (int)(((size_t)c->KP * c->nA + 255) / 256);
   HIPCHK(hipMalloc(&c->prior, sizeof(double) * 2 * (size_t)c->n_prior_blocks));
   HIPCHK(hipMalloc(&c->scal, sizeof(double) * 8));
@@ -1586,6 +1641,7 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   if (rawm) hipFree(rawm);
   if (rc != NBMF_OK) return rc;
   if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "internal: pack did not settle on a storage path");
+  if (int rc2 = setup_workspaces(c)) return rc2;
   c->n_obs = (mask_kind == NBMF_MASK_NONE) ? (double)c->m * (double)c->n : (double)st[0];
   c->n_obs_global = c->n_obs;
   hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
