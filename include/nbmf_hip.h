@@ -94,8 +94,9 @@ int nbmf_loss(nbmf_ctx* ctx, double* loss);
 
 /* Sum over entries of Ym*log(Theta+eps) + (1-Ym)*log(1-Theta+eps) for the current factors (summed over
  * ranks when a communicator is attached): the numerator of NBMFMM.score, _base.py:239-247 (divide by
- * nbmf_get_n_obs), and the data term of the loss, _solver.py:150-154. */
-int nbmf_loglik(nbmf_ctx* ctx, double* loglik);
+ * nbmf_get_n_obs), and the data term of the loss, _solver.py:150-154.  clip_theta != 0 clips Theta to [0, 1]
+ * first, as NBMFMM.inverse_transform does (_base.py:210) before score evaluates it. */
+int nbmf_loglik(nbmf_ctx* ctx, int clip_theta, double* loglik);
 
 /* Strictly masked variant: sum over OBSERVED entries only of mask*(Y log(Theta+eps) + (1-Y) log(1-Theta+eps)),
  * the held-out log-likelihood of examples/reproduce_magron2022.py:40-47 (compute_perplexity: divide by

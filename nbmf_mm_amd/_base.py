@@ -134,19 +134,7 @@ class NBMFMM(BaseEstimator, TransformerMixin):
         if mask is not None and hasattr(mask, "toarray"):
             mask = mask.toarray()
         H = np.asarray(self.components_, dtype=np.float64)
-        if H.min() >= 0.0 and H.max() <= 1.0:
-            return device_score(X, H, mask=mask, n_iter=50, device=self.device)
-        # components_ outside [0, 1] (set by hand): the clip of inverse_transform matters -> host formula
-        recon = self.inverse_transform(self.transform(X))
-        eps = 1e-8
-        if mask is None:
-            ll = X * np.log(recon + eps) + (1 - X) * np.log(1 - recon + eps)
-            n_obs = X.size
-        else:
-            xm = X * mask
-            ll = xm * np.log(recon + eps) + (1 - xm) * np.log(1 - recon + eps)
-            n_obs = np.count_nonzero(mask)
-        return float(np.sum(ll) / n_obs)
+        return device_score(X, H, mask=mask, n_iter=50, device=self.device)
 
     def perplexity(self, X, mask=None):
         """exp(-score) (_base.py:249-265)."""

@@ -75,7 +75,7 @@ def load():
     lib.nbmf_run.argtypes = [c_void_p, c_int, c_double, c_void_p, POINTER(c_int)]
     lib.nbmf_w_only_steps.argtypes = [c_void_p, c_int]
     lib.nbmf_loss.argtypes = [c_void_p, dp]
-    lib.nbmf_loglik.argtypes = [c_void_p, dp]
+    lib.nbmf_loglik.argtypes = [c_void_p, c_int, dp]
     lib.nbmf_loglik_strict.argtypes = [c_void_p, dp]
     lib.nbmf_comm_unique_id.argtypes = [c_void_p]
     lib.nbmf_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int]
@@ -198,10 +198,11 @@ class Context:
         _check(self._lib.nbmf_loss(self._h, byref(v)))
         return v.value
 
-    def loglik(self):
-        """Data log-likelihood sum of the current factors (no prior, not divided by n_obs)."""
+    def loglik(self, clip_theta=False):
+        """Data log-likelihood sum of the current factors (no prior, not divided by n_obs);
+        clip_theta clips W^T H to [0, 1] first (the reference's inverse_transform)."""
         v = c_double(0)
-        _check(self._lib.nbmf_loglik(self._h, byref(v)))
+        _check(self._lib.nbmf_loglik(self._h, int(bool(clip_theta)), byref(v)))
         return v.value
 
     def loglik_strict(self):

@@ -130,8 +130,7 @@ def w_only_transform(X, H, mask=None, W0=None, n_iter=50, device=0):
 def device_score(X, H, mask=None, n_iter=50, device=0):
     """``NBMFMM.score`` on the GPU (src/nbmf_mm/_base.py:212-247): the inner transform runs WITHOUT
     the mask (:235), then the mean log-likelihood per observed entry of W @ H under ``mask``.
-    The reference clips W @ H to [0, 1] (:210); with rows of W on the simplex and H in [0, 1] the
-    product already lies there up to rounding, so the clip is not applied on the device."""
+    The reference clips W @ H to [0, 1] first (:210); so does the device sweep (clip_theta)."""
     X = np.asarray(X, dtype=np.float64)
     m, n = X.shape
     k = H.shape[0]
@@ -147,6 +146,6 @@ def device_score(X, H, mask=None, n_iter=50, device=0):
         if mask is not None:
             ctx.upload(X, mask=mask, transposed=False)
         ctx.set_factors(np.ascontiguousarray(W.T), H)
-        ll = ctx.loglik()
+        ll = ctx.loglik(clip_theta=True)
         n_obs = ctx.n_obs()
     return float(ll / n_obs)

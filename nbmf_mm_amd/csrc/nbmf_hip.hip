@@ -164,6 +164,7 @@ struct PassArgs {
   long long C_alloc;    // 16*Cb
   double eps;
   int strict;           // MODE_L: 1 = only observed entries enter the likelihood; 0 = the loss's semantics (as MODE_H)
+  int clip;             // MODE_L: 1 = clip Theta to [0, 1] first (NBMFMM.inverse_transform, _base.py:210)
 };
 
 template <int KB, int DATA, int MODE>
@@ -354,6 +355,10 @@ __global__ __launch_bounds__(256, (NBMF_STAGE_HALF && KB <= 4) ? 3 : ((KB <= 4 |
         }
       }
       if (DUAL) th += th2;
+      if (MODE == MODE_L && a.clip) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) th[r] = fmin(fmax(th[r], 0.0), 1.0);
+      }
 
       // first back-product operand group: issued now, lands during the ratio arithmetic
       double gcur[GB];
@@ -1284,7 +1289,7 @@ int enqueue_h_pass(nbmf_ctx* c) {
 
 // Theta-only sweep (no back-products): the log-likelihood of the current factors at a third of the
 // H-pass's MFMA work; the per-wave partials land in lossbuf exactly as an H-pass leaves them.
-int enqueue_loglik_pass(nbmf_ctx* c, int strict) {
+int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0) {
   PassArgs a{};
   a.data = c->dataA;
   a.mask = c->maskA;
@@ -1301,6 +1306,7 @@ int enqueue_loglik_pass(nbmf_ctx* c, int strict) {
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.strict = strict;
+  a.clip = clip;
   HIPCHK(launch_pass<MODE_L>(c->KB, c->data_kind, a, c->chunksH, c->stream));
   if (int rc = enqueue_exchange_after_sweep(c, a, /*with_products=*/false, strict)) return rc;
   return NBMF_OK;
@@ -1814,13 +1820,13 @@ int nbmf_loss(nbmf_ctx* c, double* loss) {
   return NBMF_OK;
 }
 
-int nbmf_loglik(nbmf_ctx* c, double* loglik) {
+int nbmf_loglik(nbmf_ctx* c, int clip_theta, double* loglik) {
   if (int rc = ready(c)) return rc;
   if (!loglik) return fail(NBMF_ERR_ARG, "null output");
   if (int rc = set_device(c)) return rc;
   if (int rc = ensure_losses(c, 1)) return rc;
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
-  if (int rc = enqueue_loglik_pass(c, 0)) return rc;
+  if (int rc = enqueue_loglik_pass(c, 0, clip_theta != 0)) return rc;
   if (int rc = enqueue_finalize(c, 0, 0.0, /*loglik_only=*/true)) return rc;   // -(ll + 0 + 0) / -1 = ll
   HIPCHK(hipMemcpyAsync(loglik, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

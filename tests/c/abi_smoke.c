@@ -44,7 +44,7 @@ int main(void) {
   CK(nbmf_run(ctx, ITERS, 0.0, losses, &n_iter));
   CK(nbmf_get_factors(ctx, W, H));
   CK(nbmf_loss(ctx, &loss_now));
-  CK(nbmf_loglik(ctx, &ll));
+  CK(nbmf_loglik(ctx, 0, &ll));
   CK(nbmf_destroy(ctx));
   if (n_iter != ITERS) return 5;
   for (i = 1; i < ITERS; ++i) if (!(losses[i] <= losses[i - 1] + 1e-12)) { fprintf(stderr, "loss not monotone at %d\n", i); return 6; }

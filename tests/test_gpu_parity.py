@@ -224,10 +224,16 @@ def test_transform_score_perplexity(hip, golden):
         assert abs(dev - float(g[key])) <= 1e-12 * abs(float(g[key]))
     np.random.seed(6)
     assert abs(mdl.perplexity(X, mask=maskf) - float(g["perplexity"])) <= 5e-3 * float(g["perplexity"])
-    # components_ outside [0,1] (set by hand) takes the host formula with the reference's clip
-    mdl.components_ = g["H"] * 1.5
-    np.random.seed(6)
-    assert np.isfinite(mdl.score(X))
+    # the reference clips W @ H to [0, 1] before the logs (_base.py:210): with components_ pushed outside
+    # [0, 1] by hand the clipped device sweep still agrees with the oracle's formula on pinned W
+    Hbig = np.clip(g["H"] * 1.6, 0, None)
+    with hip.Context(100, 500, 6) as ctx:
+        ctx.set_hyper(1.2, 1.2)
+        ctx.upload(X, mask=maskf)
+        ctx.set_factors(np.ascontiguousarray(W_pin.T), Hbig)
+        dev = ctx.loglik(clip_theta=True) / ctx.n_obs()
+    want = orc.score(X, W_pin, Hbig, maskf)
+    assert (W_pin @ Hbig).max() > 1.0 and abs(dev - want) <= 1e-12 * abs(want)
 
 
 def test_midsize_curves(hip, golden):
