@@ -1321,7 +1321,8 @@ int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false, i
   // axis 1: the prior sums were exchanged with the log-likelihood
   const bool prior_x = sh && c->shard_axis == 1;
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, ll_src, n_ll, pad,
-                     prior_x ? (const double*)(c->sbuf + 1) : (const double*)c->prior, prior_x ? 1 : c->n_prior_blocks,
+                     prior_x ? (const double*)(c->sbuf + 1) : (const double*)c->prior,
+                     loglik_only ? 0 : (prior_x ? 1 : c->n_prior_blocks),   // no prior term (and no 0 x NaN) in a pure log-likelihood
                      loglik_only ? 0.0 : c->alpha - 1.0, loglik_only ? 0.0 : c->beta - 1.0,
                      loglik_only ? -1.0 : c->n_obs_global, c->losses_d, t, tol, c->scal, c->flags);
   HIPCHK(hipGetLastError());
