@@ -1,0 +1,96 @@
+"""The reference's behavioural contract (its tests/ directory) re-stated against the drop-in:
+shapes, constraints, monotone loss, aliases, reproducibility, sklearn protocol, extensions."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def data():
+    from nbmf_mm_amd._utils import generate_synthetic_binary_data
+    X, _, _ = generate_synthetic_binary_data(60, 45, 5, random_state=42)
+    return X
+
+
+def test_shapes_constraints_both_orientations(data):
+    from nbmf_mm_amd import NBMF
+    for orient, simplex_rows in [("beta-dir", True), ("dir-beta", False)]:
+        m = NBMF(n_components=5, orientation=orient, max_iter=100, tol=1e-8, random_state=0).fit(data)
+        assert m.W_.shape == (60, 5) and m.components_.shape == (5, 45)
+        if simplex_rows:       # tests/test_algorithm_correctness.py:25-39,5-23
+            np.testing.assert_allclose(m.W_.sum(axis=1), 1.0, rtol=1e-5)
+            cont = m.components_
+        else:                  # :129-143,109-127
+            np.testing.assert_allclose(m.components_.sum(axis=0), 1.0, rtol=1e-5)
+            cont = m.W_
+        assert cont.min() >= 0 and cont.max() <= 1 and len(np.unique(cont)) > 100
+        l = m.loss_curve_
+        assert all(l[i] <= l[i - 1] + 1e-12 for i in range(1, len(l)))          # :41-60
+        assert len(m.objective_history_) == m.n_iter_ and m.loss_ == l[-1] == m.reconstruction_err_
+        assert isinstance(m.reconstruction_err_, float)
+        recon = m.inverse_transform(m.W_)
+        assert recon.shape == data.shape and len(np.unique(recon)) > 100           # :62-81
+
+
+def test_aliases_are_normalised_and_written_back(data):
+    from nbmf_mm_amd import NBMF
+    for alias, norm in [("Dir-Beta", "dir-beta"), ("Aspect Bernoulli", "dir-beta"), ("binary ICA", "beta-dir"),
+                        ("Binary ICA", "beta-dir"), ("bICA", "beta-dir"), ("Beta-Dir", "beta-dir"), ("Dir Beta", "dir-beta")]:
+        m = NBMF(n_components=3, orientation=alias, max_iter=5, random_state=0).fit(data)
+        assert m.orientation == norm                                              # tests/test_api.py:139-153
+    a = NBMF(n_components=4, orientation="Aspect Bernoulli", max_iter=20, tol=0, random_state=0).fit(data)
+    b = NBMF(n_components=4, orientation="binary ICA", max_iter=20, tol=0, random_state=0).fit(data.T)
+    np.testing.assert_array_equal(a.W_, b.components_.T)                          # tests/test_symmetry.py (bitwise here)
+
+
+def test_fit_transform_transform_score(data):
+    from nbmf_mm_amd import NBMF
+    m = NBMF(n_components=5, max_iter=60, random_state=0)
+    Wt = m.fit_transform(data)
+    np.testing.assert_array_equal(Wt, m.W_)                                       # tests/test_public_api.py:34-41
+    W2 = m.transform(data[:7])
+    assert W2.shape == (7, 5)
+    np.testing.assert_allclose(W2.sum(axis=1), 1.0, atol=1e-12)
+    mask = np.random.default_rng(0).random(data.shape) < 0.8
+    mm = NBMF(n_components=5, max_iter=60, random_state=0).fit(data, mask=mask)
+    s = mm.score(data, mask=mask)
+    assert isinstance(s, float) and np.isfinite(s) and mm.perplexity(data, mask=mask) >= 1.0   # tests/test_api.py:73-85
+
+
+def test_reproducibility_and_seed_dependence(data):
+    from nbmf_mm_amd import NBMF
+    a = NBMF(n_components=5, random_state=42, max_iter=50).fit(data)
+    b = NBMF(n_components=5, random_state=42, max_iter=50).fit(data)
+    c = NBMF(n_components=5, random_state=43, max_iter=50).fit(data)
+    np.testing.assert_array_equal(a.components_, b.components_)                   # tests/test_nbmf_mm.py:127-138
+    np.testing.assert_array_equal(a.W_, b.W_)
+    assert abs(a.loss_ - b.loss_) < 1e-8 and not np.allclose(a.components_, c.components_)   # tests/test_reproducibility.py
+
+
+def test_tolerance_controls_iterations(data):
+    from nbmf_mm_amd import NBMFMM
+    hi = NBMFMM(n_components=5, tol=0.1, max_iter=1000, random_state=42).fit(data)
+    lo = NBMFMM(n_components=5, tol=1e-8, max_iter=1000, random_state=42).fit(data)
+    assert hi.n_iter_ < 50 < lo.n_iter_                                           # tests/test_nbmf_mm.py:113-125
+
+
+def test_prior_effect_ordering(data):
+    from nbmf_mm_amd import NBMF
+    lo = NBMF(n_components=4, alpha=1.0, beta=3.0, max_iter=150, random_state=0).fit(data).components_.mean()
+    hi = NBMF(n_components=4, alpha=3.0, beta=1.0, max_iter=150, random_state=0).fit(data).components_.mean()
+    assert hi > lo                                                                # tests/test_algorithm_correctness.py:83-107
+
+
+def test_extensions_n_init_projection_verbose(data, capsys):
+    from nbmf_mm_amd import NBMF
+    single = [NBMF(n_components=4, max_iter=30, tol=0, random_state=5 + i).fit(data).loss_ for i in range(3)]
+    best = NBMF(n_components=4, max_iter=30, tol=0, random_state=5, n_init=3).fit(data)
+    assert best.loss_ == min(single)
+    d = NBMF(n_components=4, max_iter=30, tol=0, random_state=5, projection_method="duchi").fit(data)
+    np.testing.assert_allclose(d.W_.sum(axis=1), 1.0, atol=1e-12)
+    NBMF(n_components=3, max_iter=25, tol=0, random_state=0, verbose=1).fit(data)
+    out = capsys.readouterr().out
+    assert "Iter    0: Loss = " in out and "Iter   20: Loss = " in out           # _solver.py:165-166 text
+    with pytest.raises(ValueError, match="n_components"):
+        NBMF(n_components=129, max_iter=2).fit(data)                              # K > 128 is refused loudly
