@@ -7,6 +7,11 @@ no distributed counterpart; arithmetic differs from the single-GPU run by summat
 
 torch.distributed (gloo) is used for rendezvous only: broadcasting the 128-byte RCCL id, barriers,
 and — in the tests / as a fallback transport — a host-mediated all-reduce.
+
+Load order: the PyTorch wheel bundles a private ROCm runtime; import torch BEFORE the first
+``nbmf_mm_amd`` context is created (callers of this module do, since they pass ``torch.distributed``
+in), otherwise RCCL resolves the HSA runtime to torch's uninitialised copy and reports "no
+ROCm-capable device".
 """
 from __future__ import annotations
 

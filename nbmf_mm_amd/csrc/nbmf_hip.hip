@@ -160,7 +160,7 @@ struct PassArgs {
   const int* done;      // device stop flag: skip all work when set
   int Rb;               // row blocks of D (multiple of 8)
   int Cb;               // column strips of D (multiple of 4)
-  int CH;               // row blocks per chunk (multiple of NB)
+  const int* chunk_start;   // [chunks + 1] row-block boundaries of the chunks (long chunks first, short ones last)
   long long C_alloc;    // 16*Cb
   double eps;
   int strict;           // MODE_L: 1 = only observed entries enter the likelihood; 0 = the loss's semantics (as MODE_H)
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256, (NBMF_STAGE_HALF && KB <= 4) ? 3 : ((KB <= 4 |
   const int wave = threadIdx.x >> 6;
   const int cb = blockIdx.x * WG_WAVES + wave;
   const int chunk = blockIdx.y;
-  const int rb0 = chunk * a.CH;
-  const int rb1 = min(rb0 + a.CH, a.Rb);
+  const int rb0 = a.chunk_start[chunk];
+  const int rb1 = a.chunk_start[chunk + 1];
   const double eps = a.eps;
 
   // stationary operand: Rf in T form for this strip
@@ -1001,6 +1001,7 @@ struct nbmf_ctx {
   double *Wn = nullptr, *WT = nullptr, *WG = nullptr, *Hn = nullptr, *HT = nullptr, *HG = nullptr;
   bool have_factors = false;
   int chunksH = 0, CH_H = 0, chunksW = 0, CH_W = 0;
+  int *cstartH = nullptr, *cstartW = nullptr;   // device: chunk boundaries of the two sweeps
   double *slabH = nullptr, *slabW = nullptr, *Pbuf = nullptr, *lossbuf = nullptr, *prior = nullptr, *scal = nullptr;
   int n_prior_blocks = 0;
   int* flags = nullptr;
@@ -1164,6 +1165,19 @@ void pick_chunks(int strips_groups, int Rb, int NB, int slots, int* chunks, int*
   *chunks = (Rb + ch - 1) / ch;
 }
 
+// Chunk boundaries (row blocks) of a sweep.  Equal chunks: cutting the tail of the sweep four times finer
+// (so that the last, lonely workgroups on a CU are short) was measured and bought nothing (c3 H-pass 3.15
+// vs 3.17 ms) while adding slabs for the update kernels to sum.
+std::vector<int> chunk_boundaries(int Rb, int ch) {
+  std::vector<int> b;
+  b.push_back(0);
+  for (int pos = 0; pos < Rb;) {
+    pos = std::min(pos + ch, Rb);
+    b.push_back(pos);
+  }
+  return b;
+}
+
 struct EvScope {
   nbmf_ctx* c;
   int kind;
@@ -1276,7 +1290,7 @@ int enqueue_h_pass(nbmf_ctx* c) {
   a.done = c->flags;
   a.Rb = (int)(c->mA / 16);
   a.Cb = (int)(c->nA / 16);
-  a.CH = c->CH_H;
+  a.chunk_start = c->cstartH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
   {
@@ -1302,7 +1316,7 @@ int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0) {
   a.done = c->flags;
   a.Rb = (int)(c->mA / 16);
   a.Cb = (int)(c->nA / 16);
-  a.CH = c->CH_H;
+  a.chunk_start = c->cstartH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.strict = strict;
@@ -1354,7 +1368,7 @@ int enqueue_w_step(nbmf_ctx* c, int projection) {
   a.done = c->flags;
   a.Rb = (int)(c->nA / 16);
   a.Cb = (int)(c->mA / 16);
-  a.CH = c->CH_W;
+  a.chunk_start = c->cstartW;
   a.C_alloc = c->mA;
   a.eps = c->eps;
   {
@@ -1402,6 +1416,18 @@ int setup_workspaces(nbmf_ctx* c) {
   const int slotsW = cus * resident_per_cu<MODE_W>(c->KB, c->data_kind);
   pick_chunks((int)(c->nA / 16 / WG_WAVES), (int)(c->mA / 16), NB, slotsH, &c->chunksH, &c->CH_H);
   pick_chunks((int)(c->mA / 16 / WG_WAVES), (int)(c->nA / 16), NB, slotsW, &c->chunksW, &c->CH_W);
+  const std::vector<int> bH = chunk_boundaries((int)(c->mA / 16), c->CH_H);
+  const std::vector<int> bW = chunk_boundaries((int)(c->nA / 16), c->CH_W);
+  c->chunksH = (int)bH.size() - 1;
+  c->chunksW = (int)bW.size() - 1;
+  for (int** p : {&c->cstartH, &c->cstartW}) {
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+  }
+  HIPCHK(hipMalloc(&c->cstartH, sizeof(int) * bH.size()));
+  HIPCHK(hipMalloc(&c->cstartW, sizeof(int) * bW.size()));
+  HIPCHK(hipMemcpy(c->cstartH, bH.data(), sizeof(int) * bH.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->cstartW, bW.data(), sizeof(int) * bW.size(), hipMemcpyHostToDevice));
   if (getenv("NBMF_DEBUG"))
     fprintf(stderr, "[nbmf] K_pad=%d path=%d: H-pass %d x %d workgroups (chunk %d blocks, %d slots), W-pass %d x %d (chunk %d, %d slots)\n",
             c->KP, c->data_kind, (int)(c->nA / 64), c->chunksH, c->CH_H, slotsH, (int)(c->mA / 64), c->chunksW, c->CH_W, slotsW);
@@ -1511,7 +1537,7 @@ int nbmf_destroy(nbmf_ctx* c) {
   if (c->host_buf) hipHostFree(c->host_buf);
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
                   c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
-                  c->sbuf, c->Qbuf};
+                  c->sbuf, c->Qbuf, c->cstartH, c->cstartW};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (hipEvent_t e : c->ev) hipEventDestroy(e);
