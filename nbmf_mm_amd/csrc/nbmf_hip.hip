@@ -136,853 +136,9 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// ------------------------------------------------------------------------------------------
-// The fused pass kernel.
-//   D      data matrix of this pass, R row blocks x C column strips of 16x16 tiles
-//   L      the factor indexed by D's rows (streamed through LDS):  LT = Theta operand, LG = back operand
-//   Rf     the factor indexed by D's columns (stationary in registers, T form)
-//   MODE_H: out1 = L (R1), out2 = L (R2)                  (P1, P2 of _solver.py:42-43)
-//   MODE_W: out1 = L (S1 - S2) + column sums of S2         (the bracket of _solver.py:53)
-//   MODE_L: no products; strictly masked log-likelihood only (held-out perplexity, evaluation)
-// Workgroup = 4 waves; wave w owns column strip 4*blockIdx.x + w and sweeps row blocks
-// [chunk*CH, chunk*CH + CH).  Partial results go to per-chunk slabs (ordered reduction later: no
-// atomics, bitwise reproducible).
-// ------------------------------------------------------------------------------------------
-struct PassArgs {
-  const void* data;     // BIN: uint32 [C strips][Rb][64] ; F64: double [C strips][Rb][64][4]
-  const void* mask;     // F64M only, same indexing as data
-  const double* LT;     // [Rb][K/4][64]
-  const double* LG;     // [Rb][K/16][4][64]
-  const double* RfT;    // [Cb][K/4][64]
-  double* out1;         // [chunks][K][C_alloc]
-  double* out2;         // MODE_H only
-  double* lossbuf;      // MODE_H/L: [chunks][Cb/4] per-workgroup log-likelihood partials
-  const int* done;      // device stop flag: skip all work when set
-  int Rb;               // row blocks of D (multiple of 8)
-  int Cb;               // column strips of D (multiple of 4)
-  const int* chunk_start;   // [chunks + 1] row-block boundaries of the chunks (long chunks first, short ones last)
-  long long C_alloc;    // 16*Cb
-  double eps;
-  int strict;           // MODE_L: 1 = only observed entries enter the likelihood; 0 = the loss's semantics (as MODE_H)
-  int clip;             // MODE_L: 1 = clip Theta to [0, 1] first (NBMFMM.inverse_transform, _base.py:210)
-};
-
-template <int KB, int DATA, int MODE>
-__global__ __launch_bounds__(256, (NBMF_STAGE_HALF && KB <= 4) ? 3 : ((KB <= 4 || MODE == MODE_W) ? 2 : 1)) void pass_kernel(PassArgs a) {
-  constexpr int K = 16 * KB;
-  constexpr int S = K / 4;            // Theta k-steps
-#if NBMF_STAGE_HALF
-  constexpr int NB = (KB >= 4) ? 1 : 4 / KB;   // experiment: 16 KiB stages -> 3 workgroups per CU
-#else
-  constexpr int NB = 8 / KB;          // row blocks per LDS stage (32 KiB)
-#endif
-  constexpr int BLK = K * 16;         // doubles per block per operand image
-  constexpr bool U8 = (NB * BLK / 2) / 256 == 8;   // 16-byte pieces per thread per image: 4, or 8 at K = 128
-  constexpr int STAGE_D = 2 * NB * BLK;   // doubles per stage: [NB][T image] then [NB][G image] (= 32 KB)
-  constexpr int N2 = NB * BLK / 2;    // double2 per image per stage (1024, or 2048 at K = 128)
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // two stages (double buffer)
-
-  if (*a.done) return;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int cb = blockIdx.x * WG_WAVES + wave;
-  const int chunk = blockIdx.y;
-  const int rb0 = a.chunk_start[chunk];
-  const int rb1 = a.chunk_start[chunk + 1];
-  const double eps = a.eps;
-
-  // stationary operand: Rf in T form for this strip
-  double rf[S];
-#pragma unroll
-  for (int s = 0; s < S; ++s) rf[s] = a.RfT[((size_t)cb * S + s) * 64 + lane];
-
-  d4 acc1[KB], acc2[KB];
-#pragma unroll
-  for (int i = 0; i < KB; ++i) {
-    acc1[i] = d4{0, 0, 0, 0};
-    acc2[i] = d4{0, 0, 0, 0};
-  }
-  double prod = 1.0;   // BIN loss: running product of the per-entry Bernoulli probabilities
-  int pexp = 0;        //           and its binary exponent
-  double llsum = 0.0;  // F64 loss
-  double s2 = 0.0;     // MODE_W: column sums of S2
-
-  const uint32_t* codes = (const uint32_t*)a.data + (size_t)cb * a.Rb * 64 + lane;
-  const d4* yv = (const d4*)a.data + (size_t)cb * a.Rb * 64 + lane;
-  const d4* mv = (const d4*)a.mask + (size_t)cb * a.Rb * 64 + lane;
-
-  // ---- staging: the operand images of NB row blocks are contiguous in HBM in exactly the LDS order,
-  //      so a stage is a linear 2 x 16 KB copy; loads are issued one stage ahead (registers), written
-  //      to the other LDS buffer after the current stage's math, one barrier per stage.
-  // (macros over named scalars, not lambdas/arrays: hipcc leaves such an array in scratch memory once
-  //  register pressure rises)
-  double2 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7, sr8, sr9, sr10, sr11, sr12, sr13, sr14, sr15;
-  uint32_t cnext[NB];
-#define STAGE_LOAD(RB)                                                          \
-  {                                                                             \
-    const double2* srcT_ = (const double2*)(a.LT + (size_t)(RB) * BLK) + threadIdx.x; \
-    const double2* srcG_ = (const double2*)(a.LG + (size_t)(RB) * BLK) + threadIdx.x; \
-    sr0 = srcT_[0];                                                             \
-    sr1 = srcT_[256];                                                           \
-    sr2 = srcT_[512];                                                           \
-    sr3 = srcT_[768];                                                           \
-    sr4 = srcG_[0];                                                             \
-    sr5 = srcG_[256];                                                           \
-    sr6 = srcG_[512];                                                           \
-    sr7 = srcG_[768];                                                           \
-    if (U8) {                                                                   \
-      sr8 = srcT_[1024];                                                        \
-      sr9 = srcT_[1280];                                                        \
-      sr10 = srcT_[1536];                                                       \
-      sr11 = srcT_[1792];                                                       \
-      sr12 = srcG_[1024];                                                       \
-      sr13 = srcG_[1280];                                                       \
-      sr14 = srcG_[1536];                                                       \
-      sr15 = srcG_[1792];                                                       \
-    }                                                                           \
-    if (DATA == DATA_BIN) {                                                     \
-      _Pragma("unroll") for (int b_ = 0; b_ < NB; ++b_) cnext[b_] = codes[(size_t)((RB) + b_) * 64]; \
-    }                                                                           \
-  }
-#define STAGE_STORE(BUF)                                                        \
-  {                                                                             \
-    double2* dst_ = (double2*)(lds + (BUF) * STAGE_D) + threadIdx.x;            \
-    dst_[0] = sr0;                                                              \
-    dst_[256] = sr1;                                                            \
-    dst_[512] = sr2;                                                            \
-    dst_[768] = sr3;                                                            \
-    dst_[N2] = sr4;                                                             \
-    dst_[N2 + 256] = sr5;                                                       \
-    dst_[N2 + 512] = sr6;                                                       \
-    dst_[N2 + 768] = sr7;                                                       \
-    if (U8) {                                                                   \
-      dst_[1024] = sr8;                                                         \
-      dst_[1280] = sr9;                                                         \
-      dst_[1536] = sr10;                                                        \
-      dst_[1792] = sr11;                                                        \
-      dst_[N2 + 1024] = sr12;                                                   \
-      dst_[N2 + 1280] = sr13;                                                   \
-      dst_[N2 + 1536] = sr14;                                                   \
-      dst_[N2 + 1792] = sr15;                                                   \
-    }                                                                           \
-  }
-
-#if NBMF_LDS_DMA
-  // Experimental alternative staging: LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no VGPRs).
-  typedef __attribute__((address_space(3))) char lds_char;
-  typedef const __attribute__((address_space(1))) char glb_char;
-#define STAGE_DMA(RB, BUF)                                                                         \
-  {                                                                                                \
-    glb_char* gT_ = (glb_char*)(a.LT + (size_t)(RB) * BLK) + lane * 16;                           \
-    glb_char* gG_ = (glb_char*)(a.LG + (size_t)(RB) * BLK) + lane * 16;                           \
-    lds_char* l_ = (lds_char*)(lds + (BUF) * STAGE_D);                                             \
-    constexpr int PIECES_ = N2 * 16 / 1024; /* 1 KiB pieces per image */                           \
-    _Pragma("unroll") for (int u_ = 0; u_ < PIECES_ / 4; ++u_) {                                   \
-      const int piece_ = wave + 4 * u_;                                                            \
-      __builtin_amdgcn_global_load_lds(gT_ + piece_ * 1024, l_ + piece_ * 1024, 16, 0, 0);        \
-      __builtin_amdgcn_global_load_lds(gG_ + piece_ * 1024, l_ + N2 * 16 + piece_ * 1024, 16, 0, 0); \
-    }                                                                                              \
-    if (DATA == DATA_BIN) {                                                                        \
-      _Pragma("unroll") for (int b_ = 0; b_ < NB; ++b_) cnext[b_] = codes[(size_t)((RB) + b_) * 64]; \
-    }                                                                                              \
-  }
-#endif
-
-  uint32_t ccur[NB];
-#if NBMF_LDS_DMA
-  STAGE_DMA(rb0, 0);
-#else
-  STAGE_LOAD(rb0);
-  STAGE_STORE(0);
-#endif
-#pragma unroll
-  for (int b = 0; b < NB; ++b) ccur[b] = cnext[b];
-  __syncthreads();
-
-  int buf = 0;
-  for (int rb = rb0; rb < rb1; rb += NB) {
-    // issue next stage's global loads now; they land while this stage computes (clamped: the last
-    // stage re-reads an in-range block, harmlessly)
-#if NBMF_LDS_DMA
-    STAGE_DMA(min(rb + NB, a.Rb - NB), buf ^ 1);   // nobody reads buf^1 between the last barrier and the next
-#else
-    STAGE_LOAD(min(rb + NB, a.Rb - NB));
-#endif
-    __builtin_amdgcn_sched_barrier(0);   // keep the loads here: hipcc otherwise sinks each one next to its ds_write
-    const double* base = lds + buf * STAGE_D;
-
-    // Operand fragments are pulled from LDS in groups of (at most) 8, one group ahead of the MFMAs that
-    // use them (8 x 64 cycles of MFMA cover the LDS latency); keeps the fragment registers at 4 x 16.
-    constexpr int GT = (S < 8) ? S : 8;          // Theta k-steps per group
-    constexpr int NGT = S / GT;
-    constexpr int PB = 4 * KB;                   // back-product operands per tile, order p = r*KB + kb
-    constexpr int GB = (PB < 8) ? PB : 8;
-    constexpr int NGB = PB / GB;
-    double tcur[GT];
-#pragma unroll
-    for (int i = 0; i < GT; ++i) tcur[i] = base[i * 64 + lane];
-
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const double* ldsT = base + b * BLK;
-      const double* ldsG = base + NB * BLK + b * BLK;
-
-      // ---- Theta tile: rows 16(rb+b)+4r+q, column 16cb+c in register r of lane (q,c).
-      // (two interleaved accumulation chains: a dependent f64 MFMA issues ~10 % slower than an
-      //  independent one when the SIMD's other wave is not there to fill the gap)
-      constexpr bool DUAL = NBMF_DUAL_THETA && (KB == 8 && MODE == MODE_H);   // only where one wave owns the SIMD
-      d4 th = {0, 0, 0, 0}, th2 = {0, 0, 0, 0};
-#pragma unroll
-      for (int g = 0; g < NGT; ++g) {
-        double tnxt[GT];
-        if (g + 1 < NGT) {
-#pragma unroll
-          for (int i = 0; i < GT; ++i) tnxt[i] = ldsT[((g + 1) * GT + i) * 64 + lane];
-          __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs that hide them
-        }
-#pragma unroll
-        for (int i = 0; i < GT; i += 2) {
-          th = __builtin_amdgcn_mfma_f64_16x16x4f64(tcur[i], rf[g * GT + i], th, 0, 0, 0);
-          if (DUAL)
-            th2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tcur[i + 1], rf[g * GT + i + 1], th2, 0, 0, 0);
-          else
-            th = __builtin_amdgcn_mfma_f64_16x16x4f64(tcur[i + 1], rf[g * GT + i + 1], th, 0, 0, 0);
-        }
-        if (g + 1 < NGT) {
-#pragma unroll
-          for (int i = 0; i < GT; ++i) tcur[i] = tnxt[i];
-        }
-      }
-      if (DUAL) th += th2;
-      if (MODE == MODE_L && a.clip) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) th[r] = fmin(fmax(th[r], 0.0), 1.0);
-      }
-
-      // first back-product operand group: issued now, lands during the ratio arithmetic
-      double gcur[GB];
-      if (MODE != MODE_L) {
-#pragma unroll
-        for (int i = 0; i < GB; ++i) gcur[i] = ldsG[((i % KB) * 4 + (i / KB)) * 64 + lane];
-      } else if (b + 1 < NB) {
-#pragma unroll
-        for (int i = 0; i < GT; ++i) tcur[i] = base[(b + 1) * BLK + i * 64 + lane];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-
-      // ---- ratios
-      double R1[4], R2[4];
-      if (DATA == DATA_BIN) {
-        const uint32_t code = ccur[b];
-        double dd[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // m = all-ones where this entry is an observed one (ym), else 0
-          const uint32_t m = (uint32_t)(-(int)((code >> (8 * r)) & 1u));
-          // d = ym ? Theta+eps : (1-Theta)+eps as fma(s, Theta, z) + eps with (s, z) = (1, 0) or (-1, 1):
-          // one rounding for 1-Theta, exact for Theta, so bit-identical to the reference expressions
-          // (including Theta > 1, which the un-normalised start of transform() can produce)
-          const double z = mk_double(0u, ~m & 0x3FF00000u);
-          const double sg = mk_double(0u, (~m & 0x80000000u) | 0x3FF00000u);
-          const double d = __builtin_fma(sg, th[r], z) + eps;
-          if (MODE == MODE_L) {
-            // strict: only observed entries (ones or zeros) enter the product; otherwise every entry
-            // does, exactly as in MODE_H (pad entries are divided out later)
-            const uint32_t keep = a.strict ? (m | (uint32_t)(-(int)((code >> (8 * r + 1)) & 1u))) : 0xFFFFFFFFu;
-            dd[r] = mk_double((uint32_t)__double2loint(d) & keep,
-                              ((uint32_t)__double2hiint(d) & keep) | (~keep & 0x3FF00000u));   // keep ? d : 1.0
-            continue;
-          }
-          const double rr = rcp_nr(d);
-          dd[r] = d;
-          const uint32_t rlo = (uint32_t)__double2loint(rr), rhi = (uint32_t)__double2hiint(rr);
-          if (MODE == MODE_H) {
-            // Every entry that is not an observed one acts as an observed zero here;
-            // pad entries have Theta == 0 exactly and their operand rows/columns are zero, so they only
-            // touch the loss product, by the constant (1+eps) that is divided out before the loss.
-            R1[r] = mk_double(rlo & m, rhi & m);        // ym ? rr : 0
-            R2[r] = mk_double(rlo & ~m, rhi & ~m);      // ym ? 0 : rr
-          } else {
-            const uint32_t zo = (uint32_t)(-(int)((code >> (8 * r + 1)) & 1u));   // observed zero
-            const uint32_t keep = m | zo;
-            R1[r] = mk_double(rlo & keep, (rhi ^ (zo & 0x80000000u)) & keep);     // S1 - S2: +rr, -rr or 0
-            s2 += mk_double(rlo & zo, rhi & zo);
-          }
-        }
-        if (MODE == MODE_H || MODE == MODE_L) {
-          prod *= (dd[0] * dd[1]) * (dd[2] * dd[3]);   // >= 1e-32 per tile: no underflow before frexp
-          int e;
-          prod = frexp(prod, &e);
-          pexp += e;
-        }
-      } else {
-        const d4 y4 = yv[(size_t)(rb + b) * 64];
-        d4 m4 = {1, 1, 1, 1};
-        if (DATA == DATA_F64M) m4 = mv[(size_t)(rb + b) * 64];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double y = y4[r];
-          const bool valid = y >= 0.0;    // pad entries are stored as -1
-          const double t = th[r];
-          const double t1 = t + eps;
-          const double t2 = (1.0 - t) + eps;
-          if (MODE == MODE_L) {
-            if (a.strict) {
-              // mask * (Y log(Theta+eps) + (1-Y) log(1-Theta+eps)): examples/reproduce_magron2022.py:40-47
-              const double wgt = (DATA == DATA_F64M) ? m4[r] : 1.0;
-              llsum += (valid && wgt != 0.0) ? wgt * (y * log_fast(t1) + (1.0 - y) * log_fast(t2)) : 0.0;
-            } else {
-              const double ym = (DATA == DATA_F64M) ? y * m4[r] : y;
-              llsum += valid ? (ym * log_fast(t1) + (1.0 - ym) * log_fast(t2)) : 0.0;   // as MODE_H, :150,154
-            }
-          } else if (MODE == MODE_H) {
-            const double ym = (DATA == DATA_F64M) ? y * m4[r] : y;    // Y*mask, _solver.py:30
-            R1[r] = valid ? ym / t1 : 0.0;                            // :42
-            R2[r] = valid ? (1.0 - ym) / t2 : 0.0;                    // :43 (1 - Y*mask)
-            llsum += valid ? (ym * log_fast(t1) + (1.0 - ym) * log_fast(t2)) : 0.0;   // :150,154
-          } else {
-            const double yo = (DATA == DATA_F64M) ? y * m4[r] : y;                 // Y.T*mask.T, :31
-            const double zo = (DATA == DATA_F64M) ? (1.0 - y) * m4[r] : (1.0 - y);  // (1-Y).T*mask.T, :32
-            const double s1v = valid ? yo / t1 : 0.0;
-            const double s2v = valid ? zo / t2 : 0.0;
-            R1[r] = s1v - s2v;
-            s2 += s2v;
-          }
-        }
-      }
-
-      // ---- back-products: accumulator registers of Theta are the B operands (rows 4r..4r+3)
-      if (MODE != MODE_L) {
-#pragma unroll
-      for (int g = 0; g < NGB; ++g) {
-        double gnxt[GB];
-        if (g + 1 < NGB) {
-#pragma unroll
-          for (int i = 0; i < GB; ++i) {
-            const int p = (g + 1) * GB + i;
-            gnxt[i] = ldsG[((p % KB) * 4 + (p / KB)) * 64 + lane];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        } else if (b + 1 < NB) {
-          // last group: fetch the first Theta group of the next tile of this stage
-#pragma unroll
-          for (int i = 0; i < GT; ++i) tcur[i] = base[(b + 1) * BLK + i * 64 + lane];
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < GB; ++i) {
-          const int p = g * GB + i, r = p / KB, kb = p % KB;
-          acc1[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(gcur[i], R1[r], acc1[kb], 0, 0, 0);
-          if (MODE == MODE_H) acc2[kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(gcur[i], R2[r], acc2[kb], 0, 0, 0);
-        }
-        if (g + 1 < NGB) {
-#pragma unroll
-          for (int i = 0; i < GB; ++i) gcur[i] = gnxt[i];
-        }
-      }
-      }
-    }
-
-    // write the prefetched stage into the other buffer; its last readers finished before the previous
-    // barrier, and this stage's readers use `buf`
-#if !NBMF_LDS_DMA
-    STAGE_STORE(buf ^ 1);
-#endif
-#pragma unroll
-    for (int b = 0; b < NB; ++b) ccur[b] = cnext[b];
-    __syncthreads();
-    buf ^= 1;
-  }
-
-  // ---- epilogue: slabs [chunk][k][column]
-  const int q = lane >> 4, c = lane & 15;
-  if (MODE == MODE_W) {
-    s2 += __shfl_xor(s2, 16, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-  }
-  double* o1 = a.out1 + (size_t)chunk * K * a.C_alloc + (size_t)cb * 16 + c;
-  double* o2 = (MODE == MODE_H) ? a.out2 + (size_t)chunk * K * a.C_alloc + (size_t)cb * 16 + c : nullptr;
-  if (MODE != MODE_L) {
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t k = 16 * kb + 4 * r + q;
-      if (MODE == MODE_H) {
-        o1[k * a.C_alloc] = acc1[kb][r];
-        o2[k * a.C_alloc] = acc2[kb][r];
-      } else {
-        o1[k * a.C_alloc] = acc1[kb][r] + s2;
-      }
-    }
-  }
-  }
-#undef STAGE_LOAD
-#undef STAGE_STORE
-  if (MODE == MODE_H || MODE == MODE_L) {
-    double ll;
-    if (DATA == DATA_BIN)
-      ll = log(prod) + (double)pexp * 0.6931471805599453094;
-    else
-      ll = llsum;
-    ll = wave_sum(ll);
-    // one partial per workgroup: the four waves in wave order (fixed -> reproducible)
-    __syncthreads();                       // all waves are done with the staging buffers
-    if (lane == 0) lds[wave] = ll;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      a.lossbuf[(size_t)chunk * gridDim.x + blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Deterministic block-wide sum (256 threads): thread t adds p[t*stride], p[(t+256)*stride], ... in
-// order, then a fixed butterfly inside each wave and the four waves in order.  Every thread must call
-// it; the result is returned to thread 0 (other threads get garbage).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double ordered_sum256(const double* __restrict__ p, int n, int stride, double* sh4) {
-  double s = 0.0;
-  for (int j = threadIdx.x; j < n; j += 256) s += p[(size_t)j * stride];
-  s = wave_sum(s);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = s;
-  __syncthreads();
-  return ((sh4[0] + sh4[1]) + sh4[2]) + sh4[3];
-}
-
-// Multi-GPU only: ordered reduction of the H-pass slabs into the all-reduce payload
-// Pbuf = [P1 | P2 | loglik]: Pbuf[t][k][j] = sum_chunks slab[t][chunk][k][j].
-__global__ __launch_bounds__(256) void reduce_h_kernel(const double* __restrict__ slab1, const double* __restrict__ slab2,
-                                                       const double* __restrict__ lossbuf, double* __restrict__ Pbuf,
-                                                       int chunks, long long per /* K_pad * nA */, int n_loss,
-                                                       double ll_pad, const int* done) {
-  __shared__ double sh4[4];
-  if (*done) return;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < per) {
-    double s1 = 0, s2 = 0;
-    for (int ch = 0; ch < chunks; ++ch) {
-      s1 += slab1[(size_t)ch * per + i];
-      s2 += slab2[(size_t)ch * per + i];
-    }
-    Pbuf[i] = s1;
-    Pbuf[per + i] = s2;
-  }
-  if (blockIdx.x == 0) {
-    const double s = ordered_sum256(lossbuf, n_loss, 1, sh4);
-    if (threadIdx.x == 0) Pbuf[2 * per] = s - ll_pad;   // binary path: pad entries each contributed log(1+eps)
-  }
-}
-
-// Column-sharded runs: ordered sums of the Beta log-prior partials into the scalar exchange slot.
-__global__ __launch_bounds__(256) void prior_reduce_kernel(const double* __restrict__ prior, int n_prior,
-                                                           double* __restrict__ out2, const int* done) {
-  __shared__ double sh4[4];
-  if (*done) return;
-  const double a = ordered_sum256(prior, n_prior, 2, sh4);
-  const double b = ordered_sum256(prior + 1, n_prior, 2, sh4);
-  if (threadIdx.x == 0) {
-    out2[0] = a;
-    out2[1] = b;
-  }
-}
-
-// Column-sharded runs: ordered sum of the W-pass slabs into the all-reduce payload Qbuf[k][i].
-__global__ __launch_bounds__(256) void reduce_w_kernel(const double* __restrict__ slab, double* __restrict__ Qbuf,
-                                                       int chunks, long long per, const int* done) {
-  if (*done) return;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= per) return;
-  double s = 0;
-  for (int ch = 0; ch < chunks; ++ch) s += slab[(size_t)ch * per + i];
-  Qbuf[i] = s;
-}
-
-// Sharded evaluation sweeps: ordered sum of the log-likelihood partials into the all-reduce slot.
-__global__ __launch_bounds__(256) void ll_reduce_kernel(const double* __restrict__ lossbuf, int n_loss, double ll_pad,
-                                                        double* __restrict__ out, const int* done) {
-  __shared__ double sh4[4];
-  if (*done) return;
-  const double s = ordered_sum256(lossbuf, n_loss, 1, sh4);
-  if (threadIdx.x == 0) *out = s - ll_pad;
-}
-
-// Beta log-prior sums of H (natural layout), per-block partials -> prior[blk][2] (_solver.py:158-159).
-__device__ __forceinline__ void block_sum2(double a, double b, double* out2) {
-  __shared__ double sh[2][8];
-  a = wave_sum(a);
-  b = wave_sum(b);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    sh[0][w] = a;
-    sh[1][w] = b;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double x = 0, y = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
-      x += sh[0][i];
-      y += sh[1][i];
-    }
-    out2[0] = x;
-    out2[1] = y;
-  }
-}
-
-// H-update (_solver.py:42-47); P1/P2 are summed here over `chunks` partial slabs in chunk order
-// (single GPU: the H-pass slabs; multi-GPU: the all-reduced Pbuf, chunks = 1).  Writes natural, T and
-// G forms.  One thread per (k, j); j fastest.
-__global__ __launch_bounds__(256) void h_update_kernel(const double* __restrict__ src1, const double* __restrict__ src2,
-                                                       int chunks, double* __restrict__ Hn, double* __restrict__ HT,
-                                                       double* __restrict__ HG, double* __restrict__ prior, int K, int KP,
-                                                       long long n, long long nA, double am1, double bm1, double eps,
-                                                       const int* done) {
-  if (*done) return;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long k = idx / nA, j = idx % nA;
-  const size_t per = (size_t)KP * nA;
-  double la = 0, lb = 0;
-  if (k < KP) {
-    double h = 0.0;
-    if (k < K && j < n) {
-      double p1 = 0, p2 = 0;
-      for (int ch = 0; ch < chunks; ++ch) {
-        p1 += src1[(size_t)ch * per + idx];
-        p2 += src2[(size_t)ch * per + idx];
-      }
-      const double hold = Hn[idx];
-      const double num = hold * p1 + am1;             // :42
-      const double den = (1.0 - hold) * p2 + bm1;     // :43
-      h = num / (num + den + eps);                    // :46
-      h = (h < eps) ? eps : ((h > 1.0 - eps) ? 1.0 - eps : h);   // np.clip, :47 (a NaN stays a NaN, as in NumPy)
-      la = log(h + eps);                              // :158
-      lb = log(1.0 - h + eps);                        // :159
-    }
-    Hn[idx] = h;
-    const long long jb = j >> 4, c = j & 15;
-    HT[(jb * KP + k) * 16 + c] = h;
-    HG[jb * KP * 16 + (k >> 4) * 256 + c * 16 + (k & 15)] = h;
-  }
-  block_sum2(la, lb, prior + 2 * (size_t)blockIdx.x);
-}
-
-// Prior sums only (used after nbmf_set_factors).
-__global__ __launch_bounds__(256) void prior_kernel(const double* __restrict__ Hn, double* __restrict__ prior, int K,
-                                                    int KP, long long n, long long nA, double eps) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long k = idx / nA, j = idx % nA;
-  double la = 0, lb = 0;
-  if (k < K && j < n) {
-    const double h = Hn[idx];
-    la = log(h + eps);
-    lb = log(1.0 - h + eps);
-  }
-  block_sum2(la, lb, prior + 2 * (size_t)blockIdx.x);
-}
-
-// Loss assembly + stop rule (_solver.py:158-175), one 256-thread block.
-//   ll = ordered sum of ll_src[0..n_ll) - ll_pad   (single GPU: the per-wave H-pass partials;
-//                                                     multi-GPU: the all-reduced Pbuf tail, n_ll = 1)
-//   scal[0] = previous loss, flags[0] = done, flags[1] = n_iter
-__global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict__ ll_src, int n_ll, double ll_pad,
-                                                       const double* __restrict__ prior, int n_prior, double am1,
-                                                       double bm1, double n_obs, double* __restrict__ losses, int t,
-                                                       double tol, double* __restrict__ scal, int* __restrict__ flags) {
-  __shared__ double sh[3][4];
-  if (flags[0]) return;
-  if (t < 0) {
-    // replayed (hipGraph) form: the loss index lives on the device; the very first call of a run only
-    // arms the counter (the H-pass of iteration 0 has no finished iteration to score)
-    const int armed = flags[3];
-    __syncthreads();
-    if (!armed) {
-      if (threadIdx.x == 0) flags[3] = 1;
-      return;
-    }
-    t = flags[2];
-  }
-  // three ordered sums in one sweep (same per-thread / butterfly / wave order as ordered_sum256, so the
-  // single-GPU and the all-reduced paths agree bit for bit); the loads of the three streams overlap
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  const int n_max = n_ll > n_prior ? n_ll : n_prior;
-#pragma unroll 4
-  for (int j = threadIdx.x; j < n_max; j += 256) {
-    if (j < n_ll) s0 += ll_src[j];
-    if (j < n_prior) {
-      s1 += prior[2 * (size_t)j];
-      s2 += prior[2 * (size_t)j + 1];
-    }
-  }
-  s0 = wave_sum(s0);
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  if ((threadIdx.x & 63) == 0) {
-    sh[0][threadIdx.x >> 6] = s0;
-    sh[1][threadIdx.x >> 6] = s1;
-    sh[2][threadIdx.x >> 6] = s2;
-  }
-  __syncthreads();
-  const double ll = (((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3]) - ll_pad;
-  const double sa = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
-  const double sb = ((sh[2][0] + sh[2][1]) + sh[2][2]) + sh[2][3];
-  if (threadIdx.x == 0) {
-    const double A = am1 * sa;
-    const double B = bm1 * sb;
-    const double loss = -(ll + A + B) / n_obs;   // :162
-    losses[t] = loss;
-    flags[1] = t + 1;
-    flags[2] = t + 1;
-    if (t > 0) {
-      const double prev = scal[0];
-      if (fabs(prev - loss) / fabs(prev) < tol) flags[0] = 1;   // :169-174
-    }
-    scal[0] = loss;
-  }
-}
-
-// W-update (_solver.py:53-57).  Block = 32 columns x 8 k-groups: every thread reduces the W-pass slabs
-// for its (k, column) entries (coalesced over columns) into an LDS tile of products W*Q/div; one
-// thread per column then sums the K products in k order (the order of numpy's sum(axis=0)) and
-//   projection 0: divides by the column sum (:57);
-//   projection 1 (extension, README.md:27-35): div = per-row observed count, then Euclidean
-//                 projection onto the simplex by Michelot's active-set iteration (unique minimiser);
-// all threads write natural, T and G forms.
-constexpr int WU_COLS = 32, WU_GROUPS = 8;
-__global__ __launch_bounds__(256) void w_update_kernel(const double* __restrict__ slab, int chunks, double* __restrict__ Wn,
-                                                       double* __restrict__ WT, double* __restrict__ WG, int K, int KP,
-                                                       long long m, long long mA, double n_div,
-                                                       const double* __restrict__ rowcnt, int projection,
-                                                       const int* done) {
-  extern __shared__ __attribute__((aligned(16))) double tile[];   // [KP][WU_COLS] products, then [2][WU_COLS] scale/tau
-  if (*done) return;
-  const int c = threadIdx.x & (WU_COLS - 1), g = threadIdx.x / WU_COLS;
-  const long long i = (long long)blockIdx.x * WU_COLS + c;
-  const size_t per = (size_t)KP * mA;
-  const bool live = i < m;
-  double div = n_div;
-  if (live && projection == NBMF_PROJ_DUCHI && rowcnt) div = fmax(rowcnt[i], 1.0);
-  for (int k = g; k < K; k += WU_GROUPS) {
-    double w = 0.0;
-    if (live) {
-      double qv = 0.0;
-      for (int ch = 0; ch < chunks; ++ch) qv += slab[(size_t)ch * per + (size_t)k * mA + i];
-      w = (Wn[(size_t)k * mA + i] * qv) / div;   // :53-54
-    }
-    tile[k * WU_COLS + c] = w;
-  }
-  __syncthreads();
-  double* par = tile + (size_t)KP * WU_COLS;      // [0][c] = scale, [1][c] = tau
-  if (g == 0) {
-    double sum = 0.0;
-    for (int k = 0; k < K; ++k) sum += tile[k * WU_COLS + c];
-    double tau = 0.0, scale = 1.0;
-    if (projection == NBMF_PROJ_DUCHI) {
-      tau = (sum - 1.0) / K;
-      int cnt = K;
-      for (int it = 0; it < K; ++it) {
-        double s = 0.0;
-        int c2 = 0;
-        for (int k = 0; k < K; ++k) {
-          const double v = tile[k * WU_COLS + c];
-          if (v > tau) {
-            s += v;
-            ++c2;
-          }
-        }
-        if (c2 == 0) break;
-        const bool same = (c2 == cnt);
-        tau = (s - 1.0) / c2;
-        cnt = c2;
-        if (same) break;
-      }
-    } else {
-      scale = sum;
-    }
-    par[c] = scale;
-    par[WU_COLS + c] = tau;
-  }
-  __syncthreads();
-  const double scale = par[c], tau = par[WU_COLS + c];
-  const long long ib = i >> 4, cc = i & 15;
-  for (int k = g; k < KP; k += WU_GROUPS) {
-    double w = 0.0;
-    if (live && k < K) {
-      const double v = tile[k * WU_COLS + c];
-      w = (projection == NBMF_PROJ_DUCHI) ? fmax(v - tau, 0.0) : v / scale;   // :57
-    }
-    Wn[(size_t)k * mA + i] = w;
-    WT[(ib * KP + k) * 16 + cc] = w;
-    WG[ib * KP * 16 + (k >> 4) * 256 + cc * 16 + (k & 15)] = w;
-  }
-}
-
-// Factor upload: natural true-size [K][len] (staging) -> padded natural, T, G.
-__global__ void set_factor_kernel(const double* __restrict__ src, double* __restrict__ Fn, double* __restrict__ FT,
-                                  double* __restrict__ FG, int K, int KP, long long len, long long lenA) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)KP * lenA) return;
-  const long long k = idx / lenA, x = idx % lenA;
-  const double v = (k < K && x < len) ? src[k * len + x] : 0.0;
-  Fn[idx] = v;
-  const long long xb = x >> 4, c = x & 15;
-  FT[(xb * KP + k) * 16 + c] = v;
-  FG[xb * KP * 16 + (k >> 4) * 256 + c * 16 + (k & 15)] = v;
-}
-
-__global__ void get_factor_kernel(const double* __restrict__ Fn, double* __restrict__ dst, int K, long long len,
-                                  long long lenA) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)K * len) return;
-  const long long k = idx / len, x = idx % len;
-  dst[idx] = Fn[k * lenA + x];
-}
-
-// ------------------------------------------------------------------------------------------
-// Pack kernel: raw row-major chunk of the user's matrix -> the two tile-ordered images.
-// One wave per 16x16 tile of the user's matrix X (rows u, columns v).
-//   transposed = 0: Y = X   (i = u, j = v);   transposed = 1: Y = X^T (i = v, j = u).
-//   image A (H-pass): [strip over j][block over i][lane (q,c)][r] = Y[16ib+4r+q][16jb+c]
-//   image B (W-pass): [strip over i][block over j][lane (q,c)][r] = Y[16ib+c][16jb+4r+q]
-// stats[0] = count of observed (mask != 0) in-range entries, stats[1] = #entries outside [0,1] or
-// non-finite, stats[2] = #non-binary data entries, stats[3] = #non-binary mask entries.
-// ------------------------------------------------------------------------------------------
-struct PackArgs {
-  const double* x;        // chunk base: rows [u0, u0+urows) of X
-  const void* mask;       // same chunk of the mask or nullptr
-  int mask_kind;
-  long long ldx, ldmask;  // elements
-  long long u0, urows;    // chunk row range in X
-  long long U, V;         // X dims
-  int transposed;
-  int binary;             // 1: write byte codes, 0: write doubles (+ mask doubles)
-  void *dataA, *dataB, *maskA, *maskB;
-  long long RbA, RbB;     // row blocks of image A (= mA/16) and of image B (= nA/16)
-  unsigned long long* stats;
-  double* rowcnt;         // unused here (filled by rowcount kernel)
-};
-
-__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
-  __shared__ double tv[4][16][17];
-  __shared__ double tm[4][16][17];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int q = lane >> 4, c = lane & 15;
-  const long long vb = (long long)blockIdx.x * 4 + wave;            // tile column in X
-  const long long ub = a.u0 / 16 + blockIdx.y;                      // tile row in X
-  unsigned long long n_obs = 0, n_bad = 0, n_nonbin = 0, n_mnonbin = 0;
-  // load style "A": element (row 4r+q, col c) of the X tile
-  double va[4], ma[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long long u = ub * 16 + 4 * r + q, v = vb * 16 + c;
-    double x = -1.0, mk = 0.0;
-    if (u < a.U && u < a.u0 + a.urows && v < a.V) {
-      x = a.x[(u - a.u0) * a.ldx + v];
-      mk = 1.0;
-      if (a.mask_kind == NBMF_MASK_F64) mk = ((const double*)a.mask)[(u - a.u0) * a.ldmask + v];
-      if (a.mask_kind == NBMF_MASK_U8) mk = ((const unsigned char*)a.mask)[(u - a.u0) * a.ldmask + v] ? 1.0 : 0.0;
-      if (!(x >= 0.0 && x <= 1.0)) ++n_bad;
-      if (x != 0.0 && x != 1.0) ++n_nonbin;
-      if (mk != 0.0 && mk != 1.0) ++n_mnonbin;
-      if (mk != 0.0) ++n_obs;
-    }
-    va[r] = x;
-    ma[r] = mk;
-    tv[wave][4 * r + q][c] = x;
-    tm[wave][4 * r + q][c] = mk;
-  }
-  __syncthreads();
-  // style "B": element (row c, col 4r+q)
-  double vbv[4], mbv[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    vbv[r] = tv[wave][c][4 * r + q];
-    mbv[r] = tm[wave][c][4 * r + q];
-  }
-  // which style feeds which image
-  const double* forA_v = a.transposed ? vbv : va;
-  const double* forA_m = a.transposed ? mbv : ma;
-  const double* forB_v = a.transposed ? va : vbv;
-  const double* forB_m = a.transposed ? ma : mbv;
-  // tile coordinates in Y: ib (block over i), jb (block over j)
-  const long long ib = a.transposed ? vb : ub;
-  const long long jb = a.transposed ? ub : vb;
-  if (ib < a.RbA && jb < a.RbB) {
-    const size_t ia = ((size_t)jb * a.RbA + ib) * 64 + lane;   // image A: strip jb, block ib
-    const size_t ibx = ((size_t)ib * a.RbB + jb) * 64 + lane;  // image B: strip ib, block jb
-    if (a.binary) {
-      uint32_t ca = 0, cbb = 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        {
-          const double x = forA_v[r], mk = forA_m[r];
-          uint32_t code = 0;
-          if (x >= 0.0) code = CB_VALID | ((x != 0.0 && mk != 0.0) ? CB_YM : 0u) | ((x == 0.0 && mk != 0.0) ? CB_ZOBS : 0u);
-          ca |= code << (8 * r);
-        }
-        {
-          const double x = forB_v[r], mk = forB_m[r];
-          uint32_t code = 0;
-          if (x >= 0.0) code = CB_VALID | ((x != 0.0 && mk != 0.0) ? CB_YM : 0u) | ((x == 0.0 && mk != 0.0) ? CB_ZOBS : 0u);
-          cbb |= code << (8 * r);
-        }
-      }
-      ((uint32_t*)a.dataA)[ia] = ca;
-      ((uint32_t*)a.dataB)[ibx] = cbb;
-    } else {
-      ((d4*)a.dataA)[ia] = d4{forA_v[0], forA_v[1], forA_v[2], forA_v[3]};
-      ((d4*)a.dataB)[ibx] = d4{forB_v[0], forB_v[1], forB_v[2], forB_v[3]};
-      if (a.mask_kind != NBMF_MASK_NONE) {
-        ((d4*)a.maskA)[ia] = d4{forA_m[0], forA_m[1], forA_m[2], forA_m[3]};
-        ((d4*)a.maskB)[ibx] = d4{forB_m[0], forB_m[1], forB_m[2], forB_m[3]};
-      }
-    }
-  }
-  // integer statistics (order-independent)
-  for (int off = 32; off >= 1; off >>= 1) {
-    n_obs += __shfl_xor(n_obs, off, 64);
-    n_bad += __shfl_xor(n_bad, off, 64);
-    n_nonbin += __shfl_xor(n_nonbin, off, 64);
-    n_mnonbin += __shfl_xor(n_mnonbin, off, 64);
-  }
-  if (lane == 0) {
-    if (n_obs) atomicAdd(&a.stats[0], n_obs);
-    if (n_bad) atomicAdd(&a.stats[1], n_bad);
-    if (n_nonbin) atomicAdd(&a.stats[2], n_nonbin);
-    if (n_mnonbin) atomicAdd(&a.stats[3], n_mnonbin);
-  }
-}
-
-// Per-internal-row observed weight (Duchi extension, README.md:32-35): thread per internal row i,
-// walking image B (strip ib, blocks over j) in order -> deterministic.
-__global__ void rowcount_kernel(const void* dataB, const void* maskB, int data_kind, long long RbB, long long m,
-                                double* rowcnt) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  const long long ib = i >> 4;
-  const int c = i & 15;
-  double s = 0.0;
-  for (long long jb = 0; jb < RbB; ++jb) {
-    for (int qq = 0; qq < 4; ++qq) {
-      const size_t base = ((size_t)ib * RbB + jb) * 64 + qq * 16 + c;
-      if (data_kind == DATA_BIN) {
-        const uint32_t code = ((const uint32_t*)dataB)[base];
-        for (int r = 0; r < 4; ++r) s += ((code >> (8 * r)) & (CB_YM | CB_ZOBS)) ? 1.0 : 0.0;
-      } else {
-        const d4 y = ((const d4*)dataB)[base];
-        d4 mk = {1, 1, 1, 1};
-        if (data_kind == DATA_F64M) mk = ((const d4*)maskB)[base];
-        for (int r = 0; r < 4; ++r) s += (y[r] >= 0.0) ? mk[r] : 0.0;
-      }
-    }
-  }
-  rowcnt[i] = s;
-}
-
-__global__ void unary_test_kernel(int op, const double* __restrict__ x, double* __restrict__ out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (op == 0) ? rcp_nr(x[i]) : log_fast(x[i]);
-}
+#include "nbmf_pass_kernel.inc"
+#include "nbmf_update_kernels.inc"
+#include "nbmf_pack_kernels.inc"
 
 }  // namespace
 
@@ -1979,3 +1135,4 @@ int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y) {
 }
 
 }  // extern "C"
+
