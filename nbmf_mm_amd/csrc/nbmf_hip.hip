@@ -34,6 +34,9 @@
 
 #include "../../include/nbmf_hip.h"
 
+#ifndef NBMF_GROUP
+#define NBMF_GROUP 8   // LDS operand fragments fetched per group (one group ahead of its MFMAs)
+#endif
 #ifndef NBMF_DUAL_THETA
 #define NBMF_DUAL_THETA 1   // two interleaved Theta accumulation chains where a wave has its SIMD to itself
 #endif
