@@ -227,3 +227,27 @@ def test_column_split_of_the_internal_matrix():
         assert r["bd_cols"][5] == n2
         np.testing.assert_allclose(r["bd_cols"][2], W2, rtol=0, atol=1e-11)
         np.testing.assert_allclose(r["bd_cols"][4], l2, rtol=1e-10, atol=0)
+
+
+def test_three_ranks_uneven_shards():
+    """world = 3 (uneven 233/233/234 row shards, one GPU shared, host transport) against the single-process run."""
+    import torch.multiprocessing as mp
+    from nbmf_mm_amd import nbmf_mm_solver
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    M, N, K, Y, mask = _problem()
+    assert [r[2] - r[1] for r in res] == [233, 233, 234]
+    W1, H1, l1, _, _ = nbmf_mm_solver(Y, K, max_iter=30, tol=0, alpha=1.2, beta=1.3, mask=mask, random_state=5)
+    np.testing.assert_allclose(np.concatenate([r[3] for r in res], axis=0), W1, rtol=0, atol=1e-12)
+    for r in res:
+        np.testing.assert_allclose(r[4], H1, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(r[5], l1, rtol=1e-10, atol=0)
+        np.testing.assert_array_equal(r[4], res[0][4])
