@@ -504,3 +504,32 @@ def test_storage_path_is_decided_by_the_whole_matrix(hip):
         ctx.set_factors(W, H)
         a = ctx.loss()
     assert abs(a - orc.mm_loss(Y, W, H, mask, 1.2, 1.2)) <= 1e-12
+
+
+def test_fuzz_against_oracle(hip):
+    """Seeded random configurations: shapes straddling the 16 / 128 padding units, every K template,
+    both orientations, mask kinds (none / bool / float 0-1 / weights), real-valued data, priors on both
+    sides of 1, both projections (the Duchi extension against the oracle's restatement of it)."""
+    from nbmf_mm_amd import nbmf_mm_solver
+    r = np.random.default_rng(2024)
+    shapes = [(1, 17), (15, 16), (16, 129), (127, 128), (128, 127), (129, 255), (257, 31), (300, 513), (640, 65)]
+    for case in range(36):
+        m, n = shapes[case % len(shapes)]
+        if case % 7 == 3:
+            m, n = int(r.integers(1, 400)), int(r.integers(1, 400))
+        k = int(r.choice([1, 2, 7, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128]))
+        real = case % 5 == 4
+        Y = r.random((m, n)) if real else (r.random((m, n)) < r.uniform(0.05, 0.6)).astype(np.float64)
+        mk = case % 4
+        mask = None if mk == 0 else (r.random((m, n)) < 0.8) if mk == 1 else \
+            (r.random((m, n)) < 0.7).astype(np.float64) if mk == 2 else r.random((m, n))
+        orient = "dir-beta" if case % 3 == 1 else "beta-dir"
+        al, be = float(r.uniform(0.6, 2.5)), float(r.uniform(0.6, 2.5))
+        duchi = case % 6 == 5
+        kw = dict(max_iter=8, tol=0, alpha=al, beta=be, mask=mask, random_state=int(case), orientation=orient)
+        W, H, l, _, _ = nbmf_mm_solver(Y, k, projection="duchi" if duchi else "normalize", **kw)
+        Wr, Hr, lr, _, _ = orc.solve(Y, k, step=orc.mm_step_duchi if duchi else None, **kw)
+        tag = f"case {case}: {m}x{n} k={k} real={real} mask={mk} {orient} duchi={duchi}"
+        np.testing.assert_allclose(l, lr, rtol=1e-9 if duchi else LOSS_RTOL, atol=0, err_msg=tag)
+        np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-8 if duchi else FACTOR_ATOL, err_msg=tag)
+        np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-8 if duchi else FACTOR_ATOL, err_msg=tag)
