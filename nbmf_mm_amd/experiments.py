@@ -11,7 +11,6 @@ import time
 import numpy as np
 
 from . import _hip
-from ._dist import global_init
 
 
 def heldout_perplexity(ctx_eval, W_kxm, H_kxn):
@@ -21,22 +20,11 @@ def heldout_perplexity(ctx_eval, W_kxm, H_kxn):
     return float(np.exp(-ctx_eval.loglik_strict() / ctx_eval.n_obs()))
 
 
-def perplexity_grid(Y, train_mask, eval_masks, n_components, alphas, betas, max_iter=500, tol=1e-5,
-                    random_state=12345, device=0, dist=None):
-    """Fit beta-dir NBMF-MM on `train_mask` for every (K, alpha, beta) and report held-out perplexities.
-
-    eval_masks: dict name -> mask (e.g. {"val": val_mask, "test": test_mask}).
-    n_components: int or iterable of ints.  Returns a list of dict rows sorted by (K, alpha, beta) with
-    keys K, alpha, beta, n_iter, loss, time, and one perplexity per eval mask; every rank gets all rows.
-    """
-    Y = np.asarray(Y, dtype=np.float64)
+def _run_points(points, Y, train_mask, eval_masks, max_iter, tol, random_state, device):
+    """Grid points (K, alpha, beta) on one set of device contexts per K (data packed once per K)."""
     m, n = Y.shape
-    Ks = [int(n_components)] if np.isscalar(n_components) else [int(k) for k in n_components]
-    points = [(k, float(a), float(b)) for k in Ks for a in alphas for b in betas]
-    world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
-    mine = points[rank::world]
     rows = []
-    for k in sorted({p[0] for p in mine}):
+    for k in sorted({p[0] for p in points}):
         with _hip.Context(m, n, k, device=device) as train:
             train.upload(Y, mask=train_mask)
             evals = {}
@@ -45,8 +33,8 @@ def perplexity_grid(Y, train_mask, eval_masks, n_components, alphas, betas, max_
                     evals[name] = _hip.Context(m, n, k, device=device)
                     evals[name].set_hyper(1.0, 1.0, 1e-8)
                     evals[name].upload(Y, mask=mk)
-                for (_, a, b) in [p for p in mine if p[0] == k]:
-                    W0, H0 = global_init(m, n, k, random_state)        # same init for every grid point
+                for (_, a, b) in [p for p in points if p[0] == k]:
+                    W0, H0 = _init(m, n, k, random_state)               # same init for every grid point
                     train.set_hyper(a, b, 1e-8, _hip.PROJ_NORMALIZE)
                     train.set_factors(W0, H0)
                     t0 = time.perf_counter()
@@ -60,6 +48,44 @@ def perplexity_grid(Y, train_mask, eval_masks, n_components, alphas, betas, max_
             finally:
                 for ev in evals.values():
                     ev.close()
+    return rows
+
+
+def _init(m, n, k, random_state):
+    """Reference init rule with a PRIVATE legacy generator seeded like np.random.seed(random_state): the
+    same numbers as the global-RNG draw of _solver.py:102-129, but safe to call from several threads."""
+    rs = np.random.RandomState(random_state)
+    W0 = rs.uniform(0.1, 0.9, (m, k))
+    H0 = rs.uniform(0.1, 0.9, (k, n))
+    W = W0.T / W0.T.sum(axis=0, keepdims=True)
+    return np.ascontiguousarray(W), H0
+
+
+def perplexity_grid(Y, train_mask, eval_masks, n_components, alphas, betas, max_iter=500, tol=1e-5,
+                    random_state=12345, device=0, dist=None, concurrency=1):
+    """Fit beta-dir NBMF-MM on `train_mask` for every (K, alpha, beta) and report held-out perplexities.
+
+    eval_masks: dict name -> mask (e.g. {"val": val_mask, "test": test_mask}).
+    n_components: int or iterable of ints.  Returns a list of dict rows sorted by (K, alpha, beta) with
+    keys K, alpha, beta, n_iter, loss, time, and one perplexity per eval mask; every rank gets all rows.
+    concurrency > 1 runs that many grid points at once on this GPU (one host thread, HIP stream and set
+    of contexts each): the reference's datasets are tiny (50x85 ... 1226x285), a single fit cannot fill
+    an MI355X, several independent ones can.  Results do not depend on it.
+    """
+    Y = np.asarray(Y, dtype=np.float64)
+    Ks = [int(n_components)] if np.isscalar(n_components) else [int(k) for k in n_components]
+    points = [(k, float(a), float(b)) for k in Ks for a in alphas for b in betas]
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+    mine = points[rank::world]
+    args = (Y, train_mask, eval_masks, max_iter, tol, random_state, device)
+    conc = max(1, min(int(concurrency), len(mine)))
+    if conc == 1:
+        rows = _run_points(mine, *args)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        parts = [sorted(mine)[i::conc] for i in range(conc)]
+        with ThreadPoolExecutor(max_workers=conc) as pool:     # ctypes releases the GIL inside the library
+            rows = [r for part in pool.map(lambda pts: _run_points(pts, *args), parts) for r in part]
     if dist is not None and world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, rows)

@@ -341,6 +341,11 @@ def test_perplexity_grid_matches_reference_driver(hip):
         for name, mk in [("val", val), ("test", test)]:
             want = orc.heldout_perplexity(Y, W @ H, mk)
             assert abs(row[name + "_perplexity"] - want) <= 1e-9 * want
+    # several grid points at once (threads, one stream each): same rows
+    conc = perplexity_grid(Y, train, {"val": val, "test": test}, [4, 20], [0.5, 1.5], [1.0, 2.5], max_iter=60, tol=1e-5,
+                           concurrency=4)
+    for a, b in zip(rows, conc):
+        assert {k: v for k, v in a.items() if k != "time"} == {k: v for k, v in b.items() if k != "time"}
     # real-valued data with a weight mask goes through the f64 variant of the same sweep
     Yr, wts = r.random((40, 70)), r.random((40, 70))
     Wf = r.uniform(0.1, 0.9, (5, 40)); Wf /= Wf.sum(axis=0, keepdims=True)
