@@ -9,18 +9,14 @@ from sklearn.utils import check_array
 from ._solver import device_score, nbmf_mm_solver, w_only_transform
 from ._utils import check_is_fitted
 
-# exact-string alias table of src/nbmf_mm/_base.py:127-137 (not case-folding)
-_ORIENTATION_ALIASES = {
-    "beta-dir": "beta-dir",
-    "dir-beta": "dir-beta",
-    "Beta-Dir": "beta-dir",
-    "Dir-Beta": "dir-beta",
-    "Dir Beta": "dir-beta",
-    "binary ICA": "beta-dir",
-    "Binary ICA": "beta-dir",
-    "bICA": "beta-dir",
-    "Aspect Bernoulli": "dir-beta",
-}
+# Accepted spellings of the two orientations: the exact strings of src/nbmf_mm/_base.py:127-137
+# (matching is exact, not case-folding; the order is the reference's, it shows in the error message).
+_SPELLINGS = (
+    ("beta-dir", "beta-dir"), ("dir-beta", "dir-beta"), ("Beta-Dir", "beta-dir"), ("Dir-Beta", "dir-beta"),
+    ("Dir Beta", "dir-beta"), ("binary ICA", "beta-dir"), ("Binary ICA", "beta-dir"), ("bICA", "beta-dir"),
+    ("Aspect Bernoulli", "dir-beta"),
+)
+_ORIENTATION_ALIASES = dict(_SPELLINGS)
 
 
 class NBMFMM(BaseEstimator, TransformerMixin):
