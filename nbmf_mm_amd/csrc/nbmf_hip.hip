@@ -654,6 +654,12 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
     return fail(NBMF_ERR_HIP, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
 
   nbmf_ctx* c = new nbmf_ctx();
+  struct CtxGuard {   // a failure below releases what has been allocated so far
+    nbmf_ctx* p;
+    ~CtxGuard() {
+      if (p) nbmf_destroy(p);
+    }
+  } ctx_guard{c};
   c->device = device;
   c->m = m;
   c->n = n;
@@ -684,6 +690,7 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
   HIPCHK(hipMemset(c->scal, 0, sizeof(double) * 8));
   c->stage_bytes = (fw > fh ? fw : fh);
   HIPCHK(hipMalloc(&c->stage, c->stage_bytes));
+  ctx_guard.p = nullptr;
   *out = c;
   return NBMF_OK;
 }
@@ -756,6 +763,14 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
       std::min<int64_t>(32768 * 16, std::max<int64_t>(PAD, ((int64_t)(256ll << 20) / (V * 8)) / PAD * PAD));
   double* raw = nullptr;
   void* rawm = nullptr;
+  struct StagingGuard {   // the raw staging buffers never outlive this call, whichever way it returns
+    double*& a;
+    void*& b;
+    ~StagingGuard() {
+      if (a) hipFree(a);
+      if (b) hipFree(b);
+    }
+  } staging_guard{raw, rawm};
   const size_t msz = mask_kind == NBMF_MASK_F64 ? 8 : 1;
   const int64_t chunk_rows = std::min<int64_t>(round_up(U, PAD), chunk_rows_max);
   HIPCHK(hipMalloc(&raw, (size_t)chunk_rows * V * 8));
@@ -829,8 +844,6 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
     c->data_kind = binary ? DATA_BIN : (mask_kind != NBMF_MASK_NONE ? DATA_F64M : DATA_F64);
     break;
   }
-  hipFree(raw);
-  if (rawm) hipFree(rawm);
   if (rc != NBMF_OK) return rc;
   if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "internal: pack did not settle on a storage path");
   if (int rc2 = setup_workspaces(c)) return rc2;
