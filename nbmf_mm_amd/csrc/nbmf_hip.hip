@@ -185,6 +185,16 @@ struct nbmf_ctx {
   double* Qbuf = nullptr;       // axis 1: reduced W-step bracket [KP][mA], the all-reduce payload
   double* sbuf = nullptr;       // scalar exchange slot: [loglik, prior A, prior B]
   const double* ll_ptr = nullptr;   // where the most recent sweep left the (global) log-likelihood
+  // axis 0: the K x N exchange is cut into column panels so that the second panel's all-reduce runs (on
+  // stream2) while the first panel's H-update and its share of the W-pass compute
+  int npanel = 1;
+  long long pc0[3] = {0, 0, 0};     // panel column boundaries
+  size_t pbase[2] = {0, 0};         // panel-major offsets into Pbuf: [P1_p (KP x wp) | P2_p (KP x wp)]
+  size_t ll_index = 0;              // loglik slot, right behind panel 0 (travels with it)
+  int wsplit = 0;                   // W-pass chunks [0, wsplit) read only panel 0's columns of H
+  std::vector<int> bW_host;         // host copy of the W-pass chunk boundaries
+  hipStream_t stream2 = nullptr;
+  hipEvent_t evH = nullptr, evF = nullptr, ev1 = nullptr;
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;   // pairs
@@ -341,7 +351,8 @@ struct EvScope {
   nbmf_ctx* c;
   int kind;
   size_t slot = (size_t)-1;
-  EvScope(nbmf_ctx* c_, int kind_) : c(c_), kind(kind_) {
+  // count = false: add the time to `kind` but do not count a launch (second part of a split sweep)
+  EvScope(nbmf_ctx* c_, int kind_, bool count = true) : c(c_), kind(kind_ | (count ? 0 : 0x100)) {
     if (!c->timing) return;
     if (c->ev_used + 2 > c->ev.size()) {
       for (int i = 0; i < 2; ++i) {
@@ -367,17 +378,17 @@ void timing_collect(nbmf_ctx* c) {
   for (size_t s = 0; s + 1 < c->ev_used; s += 2) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev[s], c->ev[s + 1]) == hipSuccess) {
-      c->t_ms[c->ev_kind[s / 2]] += ms;
-      c->t_n[c->ev_kind[s / 2]] += 1;
+      c->t_ms[c->ev_kind[s / 2] & 0xFF] += ms;
+      if (!(c->ev_kind[s / 2] & 0x100)) c->t_n[c->ev_kind[s / 2] & 0xFF] += 1;
     }
   }
   c->ev_used = 0;
 }
 
 // In-place sum over ranks of `count` doubles at device pointer `p`, on the context's stream.
-int all_reduce_inplace(nbmf_ctx* c, double* p, size_t count) {
+int all_reduce_inplace(nbmf_ctx* c, double* p, size_t count, hipStream_t st = nullptr) {
   if (c->comm) {
-    NCCLCHK(g_rccl.AllReduce(p, p, count, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    NCCLCHK(g_rccl.AllReduce(p, p, count, kNcclFloat64, kNcclSum, c->comm, st ? st : c->stream));
   } else if (c->host_reduce) {
     if (count > c->host_buf_count) return fail(NBMF_ERR_STATE, "internal: host exchange buffer too small");
     HIPCHK(hipMemcpyAsync(c->host_buf, p, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -403,7 +414,7 @@ double ll_pad_of(const nbmf_ctx* c) {
 // What travels after a sweep over image A (H-pass or Theta-only sweep), and where the global
 // log-likelihood ends up (c->ll_ptr):
 //   single GPU        nothing; finalize sums the per-wave partials itself
-//   axis 0 (rows)     H-pass: [P1 | P2 | loglik] in Pbuf; Theta-only sweep: the loglik scalar
+//   axis 0 (rows)     Theta-only sweep: the loglik scalar (the H-pass exchange is enqueue_iteration_rows)
 //   axis 1 (columns)  [loglik, prior A, prior B]: the products stay local, the scalars do not
 int enqueue_exchange_after_sweep(nbmf_ctx* c, const PassArgs& a, bool with_products, int strict) {
   const int n_loss = c->chunksH * (a.Cb / WG_WAVES);   // one log-likelihood partial per workgroup
@@ -412,15 +423,8 @@ int enqueue_exchange_after_sweep(nbmf_ctx* c, const PassArgs& a, bool with_produ
     c->ll_ptr = nullptr;
     return NBMF_OK;
   }
-  const long long per = (long long)c->KP * c->nA;
-  if (c->shard_axis == 0 && with_products) {
-    hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, a.out1, a.out2,
-                       c->lossbuf, c->Pbuf, c->chunksH, per, n_loss, pad, c->flags);
-    HIPCHK(hipGetLastError());
-    if (int rc = all_reduce_inplace(c, c->Pbuf, (size_t)(2 * per + 1))) return rc;
-    c->ll_ptr = c->Pbuf + 2 * per;
-    return NBMF_OK;
-  }
+  if (c->shard_axis == 0 && with_products)
+    return fail(NBMF_ERR_STATE, "internal: the row-split H-step exchange is driven by enqueue_iteration_rows");
   hipLaunchKernelGGL(ll_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->lossbuf, n_loss, pad, c->sbuf,
                      c->flags);
   HIPCHK(hipGetLastError());
@@ -503,18 +507,17 @@ int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false, i
 }
 
 int enqueue_h_update(nbmf_ctx* c) {
+  // single GPU or column split: sum the H-pass slabs here, all columns in one launch
   const size_t per = (size_t)c->KP * c->nA;
-  const bool reduced = is_sharded(c) && c->shard_axis == 0;     // products arrive all-reduced in Pbuf
-  const double* s1 = reduced ? c->Pbuf : c->slabH;
-  const double* s2 = reduced ? c->Pbuf + per : c->slabH + (size_t)c->chunksH * per;
-  hipLaunchKernelGGL(h_update_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, s1, s2,
-                     reduced ? 1 : c->chunksH, c->Hn, c->HT, c->HG, c->prior, c->k, c->KP, (long long)c->n,
-                     (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags);
+  hipLaunchKernelGGL(h_update_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, (const double*)c->slabH,
+                     (const double*)(c->slabH + (size_t)c->chunksH * per), c->chunksH, per, (long long)c->nA, 0LL, 0LL,
+                     (long long)c->nA, c->Hn, c->HT, c->HG, c->prior, c->k, c->KP, (long long)c->n, (long long)c->nA,
+                     c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags);
   HIPCHK(hipGetLastError());
   return NBMF_OK;
 }
 
-int enqueue_w_step(nbmf_ctx* c, int projection) {
+PassArgs w_pass_args(nbmf_ctx* c) {
   PassArgs a{};
   a.data = c->dataB;
   a.mask = c->maskB;
@@ -530,6 +533,103 @@ int enqueue_w_step(nbmf_ctx* c, int projection) {
   a.chunk_start = c->cstartW;
   a.C_alloc = c->mA;
   a.eps = c->eps;
+  return a;
+}
+
+int enqueue_w_update(nbmf_ctx* c, const double* q, int chunks, double n_div, int projection) {
+  hipLaunchKernelGGL(w_update_kernel, dim3((unsigned)(c->mA / WU_COLS)), dim3(WU_COLS * WU_GROUPS),
+                     sizeof(double) * ((size_t)c->KP + 2) * WU_COLS, c->stream, q, chunks, c->Wn, c->WT, c->WG, c->k, c->KP,
+                     (long long)c->m, (long long)c->mA, n_div, c->rowcnt, projection, c->flags);
+  HIPCHK(hipGetLastError());
+  return NBMF_OK;
+}
+
+// One whole iteration when the ROWS of Y are split over the ranks.  The exchange [P1 | P2 | loglik] is
+// cut into (at most) two column panels; panel 1's reduction + all-reduce + H-update run on stream2 while
+// stream 1 already updates panel 0 and sweeps the W-pass chunks that only read panel 0's columns of H'
+// (the W-pass is chunked over exactly that index).  With the host transport everything stays on one
+// stream (it synchronises anyway); the arithmetic is the same.
+int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
+  hipStream_t s0 = c->stream;
+  const bool two_streams = c->npanel == 2 && c->comm && c->stream2;
+  hipStream_t s1 = two_streams ? c->stream2 : s0;
+  const size_t per = (size_t)c->KP * c->nA;
+  // ---- H-pass (all columns)
+  PassArgs a{};
+  a.data = c->dataA;
+  a.mask = c->maskA;
+  a.LT = c->WT;
+  a.LG = c->WG;
+  a.RfT = c->HT;
+  a.out1 = c->slabH;
+  a.out2 = c->slabH + (size_t)c->chunksH * per;
+  a.lossbuf = c->lossbuf;
+  a.done = c->flags;
+  a.Rb = (int)(c->mA / 16);
+  a.Cb = (int)(c->nA / 16);
+  a.chunk_start = c->cstartH;
+  a.C_alloc = c->nA;
+  a.eps = c->eps;
+  {
+    EvScope ev(c, 0);
+    HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, s0));
+  }
+  if (two_streams) HIPCHK(hipEventRecord(c->evH, s0));
+  const int n_loss = c->chunksH * (a.Cb / WG_WAVES);
+  auto reduce_panel = [&](int p, hipStream_t st) -> int {
+    const long long c0 = c->pc0[p], wp = c->pc0[p + 1] - c0;
+    double* d1 = c->Pbuf + c->pbase[p];
+    double* d2 = d1 + (size_t)c->KP * wp;
+    hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)(((long long)c->KP * wp + 255) / 256)), dim3(256), 0, st,
+                       (const double*)a.out1, (const double*)a.out2, c->chunksH, (long long)per, (long long)c->nA, c0, wp,
+                       c->KP, d1, d2, (const double*)c->lossbuf, n_loss, ll_pad_of(c),
+                       p == 0 ? c->Pbuf + c->ll_index : (double*)nullptr, c->flags);
+    HIPCHK(hipGetLastError());
+    return all_reduce_inplace(c, d1, 2 * (size_t)c->KP * wp + (p == 0 ? 1 : 0), st);
+  };
+  auto update_panel = [&](int p, hipStream_t st) -> int {
+    const long long c0 = c->pc0[p], wp = c->pc0[p + 1] - c0;
+    const double* d1 = c->Pbuf + c->pbase[p];
+    const unsigned blk0 = (unsigned)((long long)c->KP * c0 / 256);
+    hipLaunchKernelGGL(h_update_kernel, dim3((unsigned)((long long)c->KP * wp / 256)), dim3(256), 0, st, d1,
+                       d1 + (size_t)c->KP * wp, 1, (size_t)0, wp, c0, c0, wp, c->Hn, c->HT, c->HG, c->prior + 2 * (size_t)blk0,
+                       c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags);
+    HIPCHK(hipGetLastError());
+    return NBMF_OK;
+  };
+  // ---- panel 0 (+ loglik) on the main stream; the loss of iteration it-1 and its stop test
+  if (int rc = reduce_panel(0, s0)) return rc;
+  c->ll_ptr = c->Pbuf + c->ll_index;
+  if (it > 0)
+    if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;
+  if (two_streams) HIPCHK(hipEventRecord(c->evF, s0));
+  // ---- panel 1 on the side stream: behind the H-pass, and its update behind the stop test
+  if (c->npanel == 2) {
+    if (two_streams) HIPCHK(hipStreamWaitEvent(s1, c->evH, 0));
+    if (int rc = reduce_panel(1, s1)) return rc;
+    if (two_streams) HIPCHK(hipStreamWaitEvent(s1, c->evF, 0));
+    if (int rc = update_panel(1, s1)) return rc;
+    if (two_streams) HIPCHK(hipEventRecord(c->ev1, s1));
+  }
+  if (int rc = update_panel(0, s0)) return rc;
+  // ---- W-pass: the chunks over panel 0's columns first, the rest once panel 1 of H' is there
+  PassArgs w = w_pass_args(c);
+  const int first = c->npanel == 2 ? c->wsplit : c->chunksW;
+  {
+    EvScope ev(c, 1);
+    HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, w, first, s0));
+  }
+  if (c->npanel == 2) {
+    if (two_streams) HIPCHK(hipStreamWaitEvent(s0, c->ev1, 0));
+    w.chunk0 = first;
+    EvScope ev(c, 1, /*count=*/false);
+    HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, w, c->chunksW - first, s0));
+  }
+  return enqueue_w_update(c, c->slabW, c->chunksW, (double)c->n, c->projection);
+}
+
+int enqueue_w_step(nbmf_ctx* c, int projection) {
+  PassArgs a = w_pass_args(c);
   {
     EvScope ev(c, 1);
     HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, a, c->chunksW, c->stream));
@@ -548,11 +648,7 @@ int enqueue_w_step(nbmf_ctx* c, int projection) {
     chunks = 1;
     n_div = c->n_div_global;
   }
-  hipLaunchKernelGGL(w_update_kernel, dim3((unsigned)(c->mA / WU_COLS)), dim3(WU_COLS * WU_GROUPS),
-                     sizeof(double) * ((size_t)c->KP + 2) * WU_COLS, c->stream, q, chunks, c->Wn, c->WT, c->WG, c->k, c->KP,
-                     (long long)c->m, (long long)c->mA, n_div, c->rowcnt, projection, c->flags);
-  HIPCHK(hipGetLastError());
-  return NBMF_OK;
+  return enqueue_w_update(c, q, chunks, n_div, projection);
 }
 
 int ensure_losses(nbmf_ctx* c, int cap) {
@@ -579,6 +675,7 @@ int setup_workspaces(nbmf_ctx* c) {
   const std::vector<int> bW = chunk_boundaries((int)(c->nA / 16), c->CH_W);
   c->chunksH = (int)bH.size() - 1;
   c->chunksW = (int)bW.size() - 1;
+  c->bW_host = bW;
   for (int** p : {&c->cstartH, &c->cstartW}) {
     if (*p) HIPCHK(hipFree(*p));
     *p = nullptr;
@@ -707,6 +804,12 @@ int nbmf_destroy(nbmf_ctx* c) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (hipEvent_t e : c->ev) hipEventDestroy(e);
+  for (hipEvent_t e : {c->evH, c->evF, c->ev1})
+    if (e) hipEventDestroy(e);
+  if (c->stream2) {
+    hipStreamSynchronize(c->stream2);
+    hipStreamDestroy(c->stream2);
+  }
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return NBMF_OK;
@@ -961,6 +1064,10 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
         HIPCHK(hipGraphLaunch(gexec, c->stream));
         continue;
       }
+      if (is_sharded(c) && c->shard_axis == 0) {
+        if (int rc = enqueue_iteration_rows(c, it, tol)) return rc;
+        continue;
+      }
       if (int rc = enqueue_h_pass(c)) return rc;
       if (it > 0)
         if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;
@@ -1059,6 +1166,25 @@ static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   c->nranks = nranks;
   c->rank = rank;
   c->shard_axis = shard_axis;
+  // row split: panels of the K x N exchange (see enqueue_iteration_rows); NBMF_NO_OVERLAP=1 keeps one
+  c->npanel = (shard_axis == 0 && c->chunksW >= 2 && !getenv("NBMF_NO_OVERLAP")) ? 2 : 1;
+  c->wsplit = c->npanel == 2 ? c->chunksW / 2 : c->chunksW;
+  c->pc0[0] = 0;
+  c->pc0[1] = c->npanel == 2 ? (long long)c->bW_host[c->wsplit] * 16 : c->nA;
+  c->pc0[2] = c->nA;
+  c->pbase[0] = 0;
+  c->ll_index = 2 * (size_t)c->KP * c->pc0[1];
+  c->pbase[1] = c->ll_index + 2;
+  if (getenv("NBMF_DEBUG"))
+    fprintf(stderr, "[nbmf] rank %d/%d axis %d: %d exchange panel(s), columns split at %lld of %lld, W-pass chunks %d + %d, %s\n",
+            rank, nranks, shard_axis, c->npanel, c->pc0[1], (long long)c->nA, c->wsplit, c->chunksW - c->wsplit,
+            c->comm ? "RCCL" : "host transport");
+  if (c->npanel == 2 && c->comm && !c->stream2) {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->evH, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->evF, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev1, hipEventDisableTiming));
+  }
   if (shard_axis == 1 && !c->Qbuf) HIPCHK(hipMalloc(&c->Qbuf, sizeof(double) * (size_t)c->KP * c->mA));
   // global observed count (the divisor of _solver.py:162) and, when the columns are split, the global
   // column count (the "/ n" of :54) and the per-row observed counts of the Duchi extension

@@ -251,3 +251,72 @@ def test_three_ranks_uneven_shards():
         np.testing.assert_allclose(r[4], H1, rtol=0, atol=1e-12)
         np.testing.assert_allclose(r[5], l1, rtol=1e-10, atol=0)
         np.testing.assert_array_equal(r[4], res[0][4])
+
+
+def _wide_problem():
+    g = np.random.default_rng(31)
+    M, N, K = 300, 2100, 10          # wide enough that the W-pass has several chunks -> two exchange panels
+    Y = (g.random((M, N)) < 0.3).astype(np.float64)
+    mask = g.random((M, N)) < 0.9
+    return M, N, K, Y, mask
+
+
+def _worker_wide(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    from nbmf_mm_amd import _dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        M, N, K, Y, mask = _wide_problem()
+        r0, r1 = _dist.shard_bounds(M, world, rank)
+        Wl, H, losses, n_iter = _dist.fit_row_sharded(Y[r0:r1], M, r0, K, dist, max_iter=200, tol=1e-4, mask_local=mask[r0:r1],
+                                                      random_state=2, device=0, transport="host")
+        q.put((rank, Wl, H, losses, n_iter))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_exchange_panels(capfd, monkeypatch):
+    """The K x N exchange cut into two column panels (second panel's all-reduce overlapping the first
+    panel's H-update and W-pass share): RCCL with one rank (two streams + events) and two ranks over the
+    host transport, against the single-process run, stop rule included."""
+    import torch.multiprocessing as mp
+    from nbmf_mm_amd import _hip, _dist, nbmf_mm_solver
+    M, N, K, Y, mask = _wide_problem()
+    W1, H1, l1, _, n1 = nbmf_mm_solver(Y, K, max_iter=200, tol=1e-4, mask=mask, random_state=2)
+    assert 5 < n1 < 200
+    monkeypatch.setenv("NBMF_DEBUG", "1")
+    W0, H0 = _dist.global_init(M, N, K, random_state=2)
+    with _hip.Context(M, N, K) as ctx:
+        ctx.set_hyper(1.2, 1.2)
+        ctx.upload(Y, mask=mask)
+        ctx.set_factors(W0, H0)
+        ctx.comm_init(_hip.comm_unique_id(), 1, 0)
+        losses, n_iter = ctx.run(200, 1e-4)
+        Wk, Hk = ctx.get_factors()
+    err = capfd.readouterr().err
+    assert "2 exchange panel(s)" in err and "RCCL" in err
+    monkeypatch.delenv("NBMF_DEBUG")
+    assert n_iter == n1
+    # (the prior partial sums are grouped per panel here: last-bit differences from the plain run)
+    np.testing.assert_allclose(losses, np.array(l1), rtol=1e-13, atol=0)
+    np.testing.assert_allclose(Wk.T, W1, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(Hk, H1, rtol=0, atol=1e-13)
+    ctx_mp = mp.get_context("spawn")
+    q = ctx_mp.Queue()
+    port = _free_port()
+    procs = [ctx_mp.Process(target=_worker_wide, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(np.concatenate([r[1] for r in res], axis=0), W1, rtol=0, atol=1e-12)
+    for r in res:
+        assert r[4] == n1
+        np.testing.assert_allclose(r[2], H1, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(r[3], l1, rtol=1e-10, atol=0)
+    np.testing.assert_array_equal(res[0][2], res[1][2])
