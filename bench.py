@@ -104,9 +104,15 @@ def main():
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host"],
                     help="all-reduce transport for --gpus > 1 (host = gloo through pinned memory; tests only)")
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events around the pass kernels (overhead check)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="row-split exchange in two panels, second one overlapped with compute (sets NBMF_OVERLAP=1)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="attach a 1-rank RCCL communicator even with --gpus 1 (rehearses the sharded code path)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
+    if args.overlap:
+        os.environ["NBMF_OVERLAP"] = "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,6 +147,9 @@ def main():
     transport = "none"
     if world > 1:
         transport = _dist.attach_comm(ctx, dist, args.transport)
+    elif args.force_comm:
+        ctx.comm_init(_hip.comm_unique_id(), 1, 0)
+        transport = "rccl(1 rank)"
 
     dev = 0 if args.share_gpu else local_rank
     if torch.cuda.is_available():

@@ -603,27 +603,35 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
   if (it > 0)
     if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;
   if (two_streams) HIPCHK(hipEventRecord(c->evF, s0));
-  // ---- panel 1 on the side stream: behind the H-pass, and its update behind the stop test
+  // ---- panel 1 on the side stream: behind the H-pass, its update behind the stop test, then straight
+  //      into the W-pass chunks that read panel 1's columns (they run beside the other half on the GPU)
+  PassArgs w = w_pass_args(c);
+  const int first = c->npanel == 2 ? c->wsplit : c->chunksW;
   if (c->npanel == 2) {
     if (two_streams) HIPCHK(hipStreamWaitEvent(s1, c->evH, 0));
     if (int rc = reduce_panel(1, s1)) return rc;
     if (two_streams) HIPCHK(hipStreamWaitEvent(s1, c->evF, 0));
     if (int rc = update_panel(1, s1)) return rc;
-    if (two_streams) HIPCHK(hipEventRecord(c->ev1, s1));
+    if (two_streams) {
+      PassArgs w1 = w;
+      w1.chunk0 = first;
+      HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, w1, c->chunksW - first, s1));
+      HIPCHK(hipEventRecord(c->ev1, s1));
+    }
   }
   if (int rc = update_panel(0, s0)) return rc;
-  // ---- W-pass: the chunks over panel 0's columns first, the rest once panel 1 of H' is there
-  PassArgs w = w_pass_args(c);
-  const int first = c->npanel == 2 ? c->wsplit : c->chunksW;
+  // ---- W-pass: the chunks over panel 0's columns on the main stream
   {
-    EvScope ev(c, 1);
+    EvScope ev(c, 1);   // with two streams: until both halves are done (includes any wait for panel 1's exchange)
     HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, w, first, s0));
-  }
-  if (c->npanel == 2) {
-    if (two_streams) HIPCHK(hipStreamWaitEvent(s0, c->ev1, 0));
-    w.chunk0 = first;
-    EvScope ev(c, 1, /*count=*/false);
-    HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, w, c->chunksW - first, s0));
+    if (c->npanel == 2) {
+      if (two_streams) {
+        HIPCHK(hipStreamWaitEvent(s0, c->ev1, 0));
+      } else {
+        w.chunk0 = first;
+        HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, w, c->chunksW - first, s0));
+      }
+    }
   }
   return enqueue_w_update(c, c->slabW, c->chunksW, (double)c->n, c->projection);
 }
@@ -1166,8 +1174,12 @@ static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   c->nranks = nranks;
   c->rank = rank;
   c->shard_axis = shard_axis;
-  // row split: panels of the K x N exchange (see enqueue_iteration_rows); NBMF_NO_OVERLAP=1 keeps one
-  c->npanel = (shard_axis == 0 && c->chunksW >= 2 && !getenv("NBMF_NO_OVERLAP")) ? 2 : 1;
+  // row split: panels of the K x N exchange (see enqueue_iteration_rows).  Two panels (NBMF_OVERLAP=1)
+  // hide half of the exchange but cost ~35 us per iteration in extra launches and a split W-pass (measured
+  // with one rank, where there is nothing to hide); the break-even is an all-reduce of ~70 us, which cannot
+  // be timed on a one-GPU box, so the default stays one panel.
+  const char* ov = getenv("NBMF_OVERLAP");
+  c->npanel = (shard_axis == 0 && c->chunksW >= 2 && ov && atoi(ov) != 0) ? 2 : 1;
   c->wsplit = c->npanel == 2 ? c->chunksW / 2 : c->chunksW;
   c->pc0[0] = 0;
   c->pc0[1] = c->npanel == 2 ? (long long)c->bW_host[c->wsplit] * 16 : c->nA;

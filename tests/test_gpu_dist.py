@@ -288,6 +288,7 @@ def test_two_exchange_panels(capfd, monkeypatch):
     W1, H1, l1, _, n1 = nbmf_mm_solver(Y, K, max_iter=200, tol=1e-4, mask=mask, random_state=2)
     assert 5 < n1 < 200
     monkeypatch.setenv("NBMF_DEBUG", "1")
+    monkeypatch.setenv("NBMF_OVERLAP", "1")          # opt-in (the spawned ranks below inherit it)
     W0, H0 = _dist.global_init(M, N, K, random_state=2)
     with _hip.Context(M, N, K) as ctx:
         ctx.set_hyper(1.2, 1.2)
