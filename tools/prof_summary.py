@@ -41,6 +41,40 @@ def main(root):
                 print("%-40s n=%-3d dur_ns=%-10.0f %s" % (k, len(dur[k]) // max(1, len(agg[k])), sum(dur[k]) / len(dur[k]), " ".join(parts)))
 
 
+def derived(root):
+    """MFMA utilisation, clock and HBM rate of the pass kernels from the PMC passes (each pass is its own
+    run, so each quantity uses the duration of the run it was collected in)."""
+    vals = collections.defaultdict(dict)
+    for d in sorted(glob.glob(f"{root}/pmc_*")):
+        for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
+            acc, dur = collections.defaultdict(lambda: collections.defaultdict(list)), collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if not k.startswith("pass_kernel"):
+                    continue
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            for k in acc:
+                t = sum(dur[k]) / len(dur[k]) * 1e-9
+                for cname, v in acc[k].items():
+                    vals[k][cname] = (sum(v) / len(v), t)
+    print("\n## derived (per launch)\n")
+    for k in sorted(vals):
+        v = vals[k]
+        out = [k]
+        if "GRBM_GUI_ACTIVE" in v:
+            cyc, t = v["GRBM_GUI_ACTIVE"][0] / 8.0, v["GRBM_GUI_ACTIVE"][1]
+            out.append("clock %.2f GHz" % (cyc / t / 1e9))
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+                out.append("MFMA busy %.1f %% of SIMD cycles (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"
+                           % (100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (cyc * 1024)))
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            b = (2.0 * v["FETCH_SIZE"][0] + v["WRITE_SIZE"][0]) * 1024.0
+            out.append("HBM traffic %.3f GB = %.2f TB/s ((2 x FETCH_SIZE + WRITE_SIZE) KiB over the fetch run's duration)"
+                       % (b / 1e9, b / v["FETCH_SIZE"][1] / 1e12))
+        print("  " + "; ".join(out))
+
+
 def sidecar(root, out_json):
     """Machine-readable extract for bench.py's roofline.traffic: per-launch means of the dominant kernel."""
     import json
@@ -64,5 +98,6 @@ def sidecar(root, out_json):
 
 if __name__ == "__main__":
     main(sys.argv[1].rstrip("/"))
+    derived(sys.argv[1].rstrip("/"))
     if len(sys.argv) > 2:
         sidecar(sys.argv[1].rstrip("/"), sys.argv[2])
