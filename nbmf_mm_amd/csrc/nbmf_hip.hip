@@ -83,7 +83,10 @@ enum { MODE_H = 0, MODE_W = 1, MODE_L = 2 };
 enum : unsigned { CB_YM = 1u, CB_ZOBS = 2u, CB_VALID = 4u };
 
 constexpr int PAD = 128;          // m and n are padded to multiples of 128 (8 row blocks, 8 strips)
-constexpr int WG_WAVES = 4;       // waves (= column strips) per workgroup of the pass kernel
+#ifndef NBMF_WG_WAVES
+#define NBMF_WG_WAVES 4
+#endif
+constexpr int WG_WAVES = NBMF_WG_WAVES;   // waves (= column strips) per workgroup of the pass kernel; measured: 2-wave workgroups run 30 % slower (125 vs 179 it/s at c3)
 constexpr int STAGE_BYTES = 32768; // one LDS stage: NB row blocks x (T + G operand images); two stages per workgroup
 
 // ------------------------------------------------------------------------------------------
@@ -258,7 +261,7 @@ hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE>), grid, dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
   return hipGetLastError();
 }
 
@@ -310,7 +313,7 @@ int resident_per_cu(int KB, int data_kind) {
   int n = 0;
   const void* f = pass_ptr<MODE>(KB, data_kind);
   const int lds_bytes = (NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES;
-  if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, lds_bytes) != hipSuccess || n < 1) n = 2;
+  if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64 * WG_WAVES, lds_bytes) != hipSuccess || n < 1) n = 2;
   return std::min(n, 8);
 }
 
