@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host"],
                     help="all-reduce transport for --gpus > 1 (host = gloo through pinned memory; tests only)")
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events around the pass kernels (overhead check)")
+    ap.add_argument("--device-data", action="store_true",
+                    help="generate the synthetic V / mask on the device (nbmf_generate) instead of uploading host arrays: "
+                         "for shapes whose float64 host array is impractical (configs[4]); no CPU baseline")
     ap.add_argument("--overlap", action="store_true",
                     help="row-split exchange in two panels, second one overlapped with compute (sets NBMF_OVERLAP=1)")
     ap.add_argument("--force-comm", action="store_true",
@@ -134,15 +137,22 @@ def main():
     from nbmf_mm_amd import _dist
     r0, r1 = _dist.shard_bounds(M, world, rank)
 
-    X, Mk = make_shard(M, N, r0, r1, args.seed, masked=masked)
     W_full, H0 = init_factors(M, N, K, args.seed)
     ctx = _hip.Context(r1 - r0, N, K, device=0 if args.share_gpu else local_rank)   # one rank = one GPU
     ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_DUCHI if args.projection == "duchi" else _hip.PROJ_NORMALIZE)
     t_up = time.perf_counter()
-    binary_path = ctx.upload(X, mask=Mk)
+    if args.device_data:
+        if world > 1:
+            raise SystemExit("--device-data is a single-GPU measurement option")
+        ctx.generate(args.seed, density=0.25, observed=0.9 if masked else 1.0)
+        binary_path, bytes_up = True, 0
+        args.no_cpu_baseline = True
+    else:
+        X, Mk = make_shard(M, N, r0, r1, args.seed, masked=masked)
+        binary_path = ctx.upload(X, mask=Mk)
+        bytes_up = X.nbytes + (Mk.nbytes if masked else 0)
+        del X, Mk
     t_up = time.perf_counter() - t_up
-    bytes_up = X.nbytes + (Mk.nbytes if masked else 0)
-    del X, Mk
     ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
     transport = "none"
     if world > 1:
@@ -190,7 +200,7 @@ def main():
         out = {
             "metric": "MM-iterations/sec", "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic (generated on device)" if args.device_data else "synthetic",
             "final_nll_per_entry": float(losses[-1]),
             "loss_monotone": bool(all(losses[i] <= losses[i - 1] + 1e-12 for i in range(1, len(losses)))),
             "config": {"workload": f"NBMF-MM fit, dense binary V {M}x{N} (float64 API, density 0.25), K={K}, "
@@ -205,7 +215,7 @@ def main():
                                          "m*N code bytes + 2*chunks*K*N*8 slab bytes = %.3g)" % (m_loc * N + 2.0 * 16 * K * N * 8),
                          "hpass_ms": h_ms, "wpass_ms": w_ms,
                          "iteration_frac": (12.0 * m_loc * N * K * its / 1e12) / PEAK_FP64_MFMA_TFLOPS},
-            "upload": {"seconds": t_up, "GBps_pcie_inclusive": bytes_up / t_up / 1e9},
+            "upload": {"seconds": t_up, "GBps_pcie_inclusive": (bytes_up / t_up / 1e9) if bytes_up else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             sample_rows = 2048

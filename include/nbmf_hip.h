@@ -72,6 +72,13 @@ int nbmf_set_hyper(nbmf_ctx* ctx, double alpha, double beta, double eps, int pro
 int nbmf_upload(nbmf_ctx* ctx, const double* x, int64_t ldx, int transposed,
                 const void* mask, int mask_kind, int64_t ldmask, int* out_flags);
 
+/* Measurement helper with no reference counterpart: fill the context with synthetic BINARY data generated on
+ * the device instead of nbmf_upload -- entry (i, j) of the internal m x n matrix is 1 with probability
+ * `density` and observed with probability `observed`, from a counter-based hash of (seed, i*n + j)
+ * (splitmix64; nbmf_mm_amd/_hip.py:synthetic_reference regenerates it in NumPy).  For shapes whose float64
+ * host array would be impractical (BASELINE configs[4]: 360k x 17k = 49 GB). */
+int nbmf_generate(nbmf_ctx* ctx, uint64_t seed, double density, double observed);
+
 /* Number of observed entries held by this context: Y.size or count_nonzero(mask), _solver.py:151,155. */
 int nbmf_get_n_obs(nbmf_ctx* ctx, double* n_obs);
 

@@ -28,7 +28,7 @@ MAX_K = 128
 #: every symbol include/nbmf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "nbmf_abi_version", "nbmf_last_error", "nbmf_device_count", "nbmf_create", "nbmf_destroy",
-    "nbmf_set_hyper", "nbmf_upload", "nbmf_get_n_obs", "nbmf_set_factors", "nbmf_get_factors",
+    "nbmf_set_hyper", "nbmf_upload", "nbmf_generate", "nbmf_get_n_obs", "nbmf_set_factors", "nbmf_get_factors",
     "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_loglik", "nbmf_loglik_strict", "nbmf_comm_unique_id", "nbmf_comm_init",
     "nbmf_comm_init_host",
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
@@ -69,6 +69,7 @@ def load():
     lib.nbmf_destroy.argtypes = [c_void_p]
     lib.nbmf_set_hyper.argtypes = [c_void_p, c_double, c_double, c_double, c_int]
     lib.nbmf_upload.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, POINTER(c_int)]
+    lib.nbmf_generate.argtypes = [c_void_p, ctypes.c_uint64, c_double, c_double]
     lib.nbmf_get_n_obs.argtypes = [c_void_p, dp]
     lib.nbmf_set_factors.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.nbmf_get_factors.argtypes = [c_void_p, c_void_p, c_void_p]
@@ -166,6 +167,11 @@ class Context:
         self.binary_path = bool(flags.value & FLAG_BINARY_PATH)
         return self.binary_path
 
+    def generate(self, seed, density=0.25, observed=1.0):
+        """Fill the context with synthetic binary data generated on the device (see synthetic_reference)."""
+        _check(self._lib.nbmf_generate(self._h, int(seed), float(density), float(observed)))
+        self.binary_path = True
+
     def n_obs(self):
         v = c_double(0)
         _check(self._lib.nbmf_get_n_obs(self._h, byref(v)))
@@ -256,3 +262,19 @@ def selftest_unary(op, x, device=0):
     _check(load().nbmf_selftest_unary(int(device), int(op), int(d.size), d.ctypes.data_as(c_void_p),
                                       out.ctypes.data_as(c_void_p)))
     return out
+
+
+def synthetic_reference(m, n, seed, density=0.25, observed=1.0):
+    """NumPy regeneration of ``Context.generate`` (same splitmix64 hash of (seed, i*n + j)): returns
+    (Y float64 m x n, mask bool m x n).  For the tests; O(m*n) host memory."""
+    def mix(x):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        idx = np.arange(m * n, dtype=np.uint64).reshape(m, n)
+        base = np.uint64(seed) * np.uint64(0x100000001B3) + idx
+        u = (mix(base) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        v = (mix(base ^ np.uint64(0xD6E8FEB86659FD93)) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return (u < density).astype(np.float64), v < observed

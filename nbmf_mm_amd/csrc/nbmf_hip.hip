@@ -971,6 +971,41 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   return NBMF_OK;
 }
 
+int nbmf_generate(nbmf_ctx* c, uint64_t seed, double density, double observed) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (!(density >= 0.0 && density <= 1.0) || !(observed >= 0.0 && observed <= 1.0))
+    return fail(NBMF_ERR_ARG, "density and observed must lie in [0, 1]");
+  if (c->comm || c->host_reduce) return fail(NBMF_ERR_STATE, "generate before attaching a communicator");
+  if (int rc = set_device(c)) return rc;
+  for (void** p : {&c->dataA, &c->dataB, &c->maskA, &c->maskB}) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  c->data_kind = -1;
+  const size_t tiles = (size_t)(c->mA / 16) * (c->nA / 16);
+  HIPCHK(hipMalloc(&c->dataA, tiles * 256));
+  HIPCHK(hipMalloc(&c->dataB, tiles * 256));
+  HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
+  dim3 grid((unsigned)(c->nA / 16 / 4), (unsigned)(c->mA / 16));
+  if (grid.y > 65535u) return fail(NBMF_ERR_ARG, "nbmf_generate supports at most 1048560 internal rows");
+  hipLaunchKernelGGL(synth_kernel, grid, dim3(256), 0, c->stream, (uint32_t*)c->dataA, (uint32_t*)c->dataB,
+                     (long long)(c->mA / 16), (long long)(c->nA / 16), (long long)c->m, (long long)c->n,
+                     (unsigned long long)seed, density, observed, c->stats);
+  HIPCHK(hipGetLastError());
+  unsigned long long st[1] = {0};
+  HIPCHK(hipMemcpyAsync(st, c->stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->data_kind = DATA_BIN;
+  if (int rc2 = setup_workspaces(c)) return rc2;
+  c->n_obs = (double)st[0];
+  c->n_obs_global = c->n_obs;
+  hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
+                     c->data_kind, (long long)(c->nA / 16), (long long)c->m, c->rowcnt);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NBMF_OK;
+}
+
 int nbmf_get_n_obs(nbmf_ctx* c, double* n_obs) {
   if (!c || !n_obs) return fail(NBMF_ERR_ARG, "null argument");
   if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "nbmf_upload has not been called");

@@ -538,3 +538,26 @@ def test_fuzz_against_oracle(hip):
         np.testing.assert_allclose(l, lr, rtol=1e-9 if duchi else LOSS_RTOL, atol=0, err_msg=tag)
         np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-8 if duchi else FACTOR_ATOL, err_msg=tag)
         np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-8 if duchi else FACTOR_ATOL, err_msg=tag)
+
+
+def test_on_device_synthetic_data_matches_its_numpy_twin(hip):
+    """Context.generate (measurement helper): the device-generated matrix equals the NumPy regeneration,
+    checked through everything the context computes from it."""
+    m, n, k = 203, 310, 9
+    Y, mask = hip.synthetic_reference(m, n, seed=77, density=0.3, observed=0.85)
+    assert 0.25 < Y.mean() < 0.35 and 0.8 < mask.mean() < 0.9
+    r = np.random.default_rng(0)
+    W = r.uniform(0.1, 0.9, (k, m)); W /= W.sum(axis=0, keepdims=True)
+    H = r.uniform(0.1, 0.9, (k, n))
+    with hip.Context(m, n, k) as gen, hip.Context(m, n, k) as up:
+        gen.set_hyper(1.2, 1.2); up.set_hyper(1.2, 1.2)
+        gen.generate(77, density=0.3, observed=0.85)
+        up.upload(Y, mask=mask)
+        assert gen.n_obs() == up.n_obs() == float(mask.sum())
+        outs = []
+        for ctx in (gen, up):
+            ctx.set_factors(W, H)
+            losses, _ = ctx.run(6, 0.0)
+            outs.append((losses,) + ctx.get_factors())
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
