@@ -34,6 +34,12 @@
 
 #include "../../include/nbmf_hip.h"
 
+#ifndef NBMF_K128_H_WAVES
+#define NBMF_K128_H_WAVES 2   // K=128 H-mode: waves per SIMD to compile for (2 needs the small operand groups below; 1 = 512-register form, 15 % slower)
+#endif
+#ifndef NBMF_K128_H_GROUP
+#define NBMF_K128_H_GROUP 2
+#endif
 #ifndef NBMF_GROUP
 #define NBMF_GROUP 8   // LDS operand fragments fetched per group (one group ahead of its MFMAs)
 #endif
