@@ -41,7 +41,7 @@
 #define NBMF_K128_H_GROUP 2
 #endif
 #ifndef NBMF_GROUP
-#define NBMF_GROUP 8   // LDS operand fragments fetched per group (one group ahead of its MFMAs)
+#define NBMF_GROUP 2   // LDS operand fragments fetched per group, one group ahead of its MFMAs (8: 2.5 % slower, more VGPRs)
 #endif
 #ifndef NBMF_DUAL_THETA
 #define NBMF_DUAL_THETA 1   // two interleaved Theta accumulation chains where a wave has its SIMD to itself
