@@ -206,6 +206,9 @@ def main():
             "config": {"workload": f"NBMF-MM fit, dense binary V {M}x{N} (float64 API, density 0.25), K={K}, "
                                    f"{'mask 90% observed' if masked else 'no mask'}, projection={args.projection}, "
                                    f"alpha=beta=1.2, tol=0 (BASELINE.json configs[2])",
+                       "note": "projection=duchi is the README-only extension BASELINE configs[2] names (no reference code: "
+                               "property-tested); --projection normalize is the reference path, same kernels and the same "
+                               "speed to within 0.2 % (DESIGN.md 5)",
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
                        "sharding": f"rows/{world} ({transport} all-reduce of 2*K*N+1 doubles per iteration)" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
