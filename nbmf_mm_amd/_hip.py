@@ -56,6 +56,13 @@ def load():
     if _lib is not None:
         return _lib
     path = library_path()
+    if not os.path.exists(path) and "NBMF_HIP_LIBRARY" not in os.environ and not os.environ.get("NBMF_NO_AUTOBUILD"):
+        # a source checkout without the built artefact: build it once if the toolchain is here
+        import shutil
+        import subprocess
+        if shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+            subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], check=False,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if not os.path.exists(path):
         raise NBMFHipError(
             f"{path} not found: build it with `make -C nbmf_mm_amd/csrc` (needs hipcc); "
