@@ -101,8 +101,9 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: --M rows PER GPU (e.g. --M 32768 --gpus 8 = BASELINE configs[3], 262144 x 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host"],
-                    help="all-reduce transport for --gpus > 1 (host = gloo through pinned memory; tests only)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "host"],
+                    help="exchange transport for --gpus > 1: peer = the library's own kernels over xGMI (HIP IPC), rccl = RCCL "
+                         "all-reduce, host = gloo through pinned memory (tests only); auto = the first of these that attaches on every rank")
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events around the pass kernels (overhead check)")
     ap.add_argument("--device-data", action="store_true",
                     help="generate the synthetic V / mask on the device (nbmf_generate) instead of uploading host arrays: "
@@ -210,7 +211,9 @@ def main():
                                "property-tested); --projection normalize is the reference path, same kernels and the same "
                                "speed to within 0.2 % (DESIGN.md 5)",
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
-                       "sharding": f"rows/{world} ({transport} all-reduce of 2*K*N+1 doubles per iteration)" if world > 1 else "none"},
+                       "sharding": (f"rows/{world} ({transport}: " + ("reduce-scatter of 2*K*N+1 doubles fused with the H-update, K*N back"
+                                                             if transport == "peer" else "all-reduce of 2*K*N+1 doubles")
+                                    + " per iteration)") if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -130,6 +130,28 @@ int nbmf_comm_init(nbmf_ctx* ctx, const void* id128, int nranks, int rank, int s
 typedef int (*nbmf_host_allreduce_fn)(void* user, double* buf, int64_t count);
 int nbmf_comm_init_host(nbmf_ctx* ctx, nbmf_host_allreduce_fn fn, void* user, int nranks, int rank, int shard_axis);
 
+/* Peer transport: the same exchanges done by the library's own kernels straight over xGMI (each rank maps
+ * every other rank's exchange arena through HIP IPC).  Axis 0 fuses the H-update into a reduce-scatter: each
+ * rank sums its 1/R column slice of [P1 | P2] in rank order, updates that slice of H and stores it into every
+ * rank's arena, so K*N instead of 2*K*N doubles travel back and the update is not repeated R times; axis 1
+ * all-reduces the W-step bracket in place (two-shot).  Sums are in rank order -> bitwise reproducible and
+ * identical on all ranks.  Every wait is bounded (NBMF_PEER_TIMEOUT_MS, default 30000): a stalled job ends
+ * with NBMF_ERR_COMM, never with a hung GPU.
+ *   1. every rank: nbmf_peer_export(ctx, shard_axis, handle)   -> NBMF_PEER_HANDLE_BYTES opaque bytes
+ *   2. all-gather the handle blocks in rank order (any host channel)
+ *   3. every rank: nbmf_comm_init_peer(ctx, all_handles, nranks, rank, shard_axis)
+ *      (maps the arenas, runs a known-answer exchange, reduces the global counts; on failure the context is
+ *       left unattached so the caller can fall back to nbmf_comm_init)
+ * One process per rank (HIP IPC does not map a handle inside the process that exported it); at most 16
+ * ranks.  No reference counterpart. */
+#define NBMF_PEER_HANDLE_BYTES 128
+int nbmf_peer_export(nbmf_ctx* ctx, int shard_axis, void* handle);
+int nbmf_comm_init_peer(nbmf_ctx* ctx, const void* handles, int nranks, int rank, int shard_axis);
+
+/* Drop the attached communicator (RCCL, host or peer): the context is a single-GPU context over its own
+ * shard again and another nbmf_comm_init* may follow.  Collective in effect: every rank must do the same. */
+int nbmf_comm_detach(nbmf_ctx* ctx);
+
 /* Measurement: HIP-event timing of the two fused pass kernels on the context's stream. */
 int nbmf_timing_enable(nbmf_ctx* ctx, int enable);
 /* ms summed over launches since enable, and launch counts; any pointer may be NULL. */

@@ -1,8 +1,8 @@
 """Row-sharded multi-GPU fit: one process per GPU, V split by contiguous row blocks.
 
 Internal (beta-dir) layout: rank r holds Y[r0:r1, :] and W[:, r0:r1]; H (k x n) is replicated.
-Per iteration the only exchange is ONE all-reduce of the H-step products [P1 | P2 | loglik]
-(2*K*N+1 doubles) — RCCL over xGMI on the library's own stream.  The reference has
+Per iteration the only exchange is ONE sum over ranks of the H-step products [P1 | P2 | loglik]
+(2*K*N+1 doubles) on the library's own stream: its own peer kernels over xGMI, or RCCL.  The reference has
 no distributed counterpart; arithmetic differs from the single-GPU run by summation order only.
 
 torch.distributed (gloo) is used for rendezvous only: broadcasting the 128-byte RCCL id, barriers,
@@ -46,13 +46,21 @@ def global_init(M, N, K, random_state, W_init=None, H_init=None):
 def attach_comm(ctx, dist, transport="rccl", shard_axis=0):
     """Join `ctx` to the job described by the initialised torch.distributed module `dist`.
 
-    transport "rccl": RCCL all-reduce on the library's stream (the product path).
-    transport "host": all-reduce through pinned host memory and gloo (tests, rehearsal on one GPU).
-    transport "auto": try RCCL; if any rank fails to load librccl the whole job agrees (one gloo
-    all-reduce of a flag) to use the host transport instead of dying.  Returns the transport used.
+    transport "peer": the library's own exchange kernels over xGMI (HIP-IPC mapped arenas; the H-update is
+                      fused into a reduce-scatter).  One process per rank.
+    transport "rccl": RCCL all-reduce on the library's stream.
+    transport "host": all-reduce through pinned host memory and `dist` (tests, rehearsal on one GPU).
+    transport "auto": peer, else RCCL, else host -- after each attempt the ranks agree (one all-reduce of a
+                      flag over `dist`) whether it worked everywhere, so the job never splits.
+    Returns the transport used.
     """
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
+
+    def everyone(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
 
     def host():
         def allreduce(arr):
@@ -60,24 +68,63 @@ def attach_comm(ctx, dist, transport="rccl", shard_axis=0):
         ctx.comm_init_host(allreduce, world, rank, shard_axis)
         return "host"
 
+    def peer():
+        handle, err = None, None
+        try:
+            handle = ctx.peer_export(shard_axis)
+        except _hip.NBMFHipError as e:
+            err = str(e)
+        table = [None] * world
+        dist.all_gather_object(table, handle)
+        if any(h is None for h in table):
+            return None, err or "another rank could not export its arena"
+        try:
+            ctx.comm_init_peer(b"".join(table), world, rank, shard_axis)
+            ok = True
+        except _hip.NBMFHipError as e:
+            ok, err = False, str(e)
+        if everyone(ok):
+            return "peer", None
+        if ok:
+            ctx.comm_detach()
+        return None, err or "another rank failed to attach"
+
+    def rccl():
+        uid, err = None, None
+        if rank == 0:
+            try:
+                uid = _hip.comm_unique_id()
+            except _hip.NBMFHipError as e:       # librccl could not be loaded
+                err = str(e)
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            return None, f"RCCL unavailable on rank 0: {err}"
+        try:
+            ctx.comm_init(box[0], world, rank, shard_axis)
+            ok = True
+        except _hip.NBMFHipError as e:
+            ok, err = False, str(e)
+        if everyone(ok):
+            return "rccl", None
+        if ok:
+            ctx.comm_detach()
+        return None, err or "another rank failed to attach"
+
     if transport == "host":
         return host()
-    if transport not in ("rccl", "auto"):
+    if transport not in ("peer", "rccl", "auto"):
         raise ValueError(f"unknown transport {transport!r}")
-    uid, err = None, None
-    if rank == 0:
-        try:
-            uid = _hip.comm_unique_id()
-        except _hip.NBMFHipError as e:       # librccl could not be loaded
-            err = str(e)
-    box = [uid]
-    dist.broadcast_object_list(box, src=0)
-    if box[0] is None:
-        if transport == "rccl":
-            raise _hip.NBMFHipError(f"RCCL unavailable on rank 0: {err}")
-        return host()
-    ctx.comm_init(box[0], world, rank, shard_axis)
-    return "rccl"
+    errors = []
+    for name, attempt in (("peer", peer), ("rccl", rccl)):
+        if transport in (name, "auto"):
+            used, err = attempt()
+            if used:
+                return used
+            errors.append(f"{name}: {err}")
+            if transport == name:
+                raise _hip.NBMFHipError("; ".join(errors))
+    return host()
 
 
 def fit_row_sharded(Y_local, M_global, r0, n_components, dist, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,

@@ -24,13 +24,14 @@ MASK_NONE, MASK_F64, MASK_U8 = 0, 1, 2
 PROJ_NORMALIZE, PROJ_DUCHI = 0, 1
 FLAG_BINARY_PATH = 1
 MAX_K = 128
+PEER_HANDLE_BYTES = 128
 
 #: every symbol include/nbmf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "nbmf_abi_version", "nbmf_last_error", "nbmf_device_count", "nbmf_create", "nbmf_destroy",
     "nbmf_set_hyper", "nbmf_upload", "nbmf_generate", "nbmf_get_n_obs", "nbmf_set_factors", "nbmf_get_factors",
     "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_loglik", "nbmf_loglik_strict", "nbmf_comm_unique_id", "nbmf_comm_init",
-    "nbmf_comm_init_host",
+    "nbmf_comm_init_host", "nbmf_peer_export", "nbmf_comm_init_peer", "nbmf_comm_detach",
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
 ]
 
@@ -88,6 +89,9 @@ def load():
     lib.nbmf_comm_unique_id.argtypes = [c_void_p]
     lib.nbmf_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int]
     lib.nbmf_comm_init_host.argtypes = [c_void_p, HOST_ALLREDUCE_FN, c_void_p, c_int, c_int, c_int]
+    lib.nbmf_peer_export.argtypes = [c_void_p, c_int, c_void_p]
+    lib.nbmf_comm_init_peer.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int]
+    lib.nbmf_comm_detach.argtypes = [c_void_p]
     lib.nbmf_timing_enable.argtypes = [c_void_p, c_int]
     lib.nbmf_timing_get.argtypes = [c_void_p, dp, POINTER(c_int), dp, POINTER(c_int)]
     lib.nbmf_synchronize.argtypes = [c_void_p]
@@ -243,6 +247,27 @@ class Context:
                 return 1
         self._host_cb = HOST_ALLREDUCE_FN(_cb)          # keep alive as long as the context
         _check(self._lib.nbmf_comm_init_host(self._h, self._host_cb, None, int(nranks), int(rank), int(shard_axis)))
+
+    def peer_export(self, shard_axis: int = 0) -> bytes:
+        """Allocate this rank's exchange arena for the peer (xGMI) transport and return its opaque
+        PEER_HANDLE_BYTES handle block; all-gather the blocks in rank order and pass them to
+        :meth:`comm_init_peer`."""
+        buf = ctypes.create_string_buffer(PEER_HANDLE_BYTES)
+        _check(self._lib.nbmf_peer_export(self._h, int(shard_axis), buf))
+        return buf.raw
+
+    def comm_init_peer(self, handles: bytes, nranks: int, rank: int, shard_axis: int = 0):
+        """Attach the peer transport (one process per rank); on failure the context stays unattached."""
+        handles = bytes(handles)
+        if len(handles) != PEER_HANDLE_BYTES * int(nranks):
+            raise ValueError(f"expected {PEER_HANDLE_BYTES} handle bytes per rank")
+        buf = ctypes.create_string_buffer(handles, len(handles))
+        _check(self._lib.nbmf_comm_init_peer(self._h, buf, int(nranks), int(rank), int(shard_axis)))
+
+    def comm_detach(self):
+        """Drop the attached communicator; every rank must do the same."""
+        _check(self._lib.nbmf_comm_detach(self._h))
+        self._host_cb = None
 
     def timing_enable(self, on=True):
         _check(self._lib.nbmf_timing_enable(self._h, int(bool(on))))

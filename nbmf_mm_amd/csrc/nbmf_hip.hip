@@ -151,6 +151,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 #include "nbmf_pass_kernel.inc"
 #include "nbmf_update_kernels.inc"
 #include "nbmf_pack_kernels.inc"
+#include "nbmf_peer_kernels.inc"
 
 }  // namespace
 
@@ -204,6 +205,23 @@ struct nbmf_ctx {
   std::vector<int> bW_host;         // host copy of the W-pass chunk boundaries
   hipStream_t stream2 = nullptr;
   hipEvent_t evH = nullptr, evF = nullptr, ev1 = nullptr;
+  // Beta log-prior partial sums the next loss assembly reads (the local array, or the arena's copy of the
+  // most recent peer H-step)
+  const double* prior_src = nullptr;
+  int n_prior_src = 0;
+  // peer transport (nbmf_peer_kernels.inc): own arena + flag block, every rank's mapping of them
+  double* arena = nullptr;
+  unsigned long long* pflags = nullptr;
+  size_t arena_doubles = 0;
+  int arena_axis = -1;
+  bool peer = false;
+  PeerView pv{};
+  std::vector<void*> peer_mapped;   // hipIpcOpenMemHandle results to close
+  unsigned long long epoch = 0, hseq = 0;
+  long long offHX = 0, offPR = 0, offSC = 0, x_doubles = 0;
+  long long sl_c0 = 0, sl_wp = 0;   // axis 0: the column slice of H this rank updates
+  int sl_slot0 = 0;
+  double *Pbuf_own = nullptr, *sbuf_own = nullptr, *Qbuf_own = nullptr;   // the private buffers while the arena stands in
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;   // pairs
@@ -398,6 +416,17 @@ void timing_collect(nbmf_ctx* c) {
 int all_reduce_inplace(nbmf_ctx* c, double* p, size_t count, hipStream_t st = nullptr) {
   if (c->comm) {
     NCCLCHK(g_rccl.AllReduce(p, p, count, kNcclFloat64, kNcclSum, c->comm, st ? st : c->stream));
+  } else if (c->peer) {
+    const long long off = p - c->arena;
+    if (off < 0 || (size_t)off + count > c->arena_doubles) return fail(NBMF_ERR_STATE, "internal: peer exchange outside the arena");
+    hipStream_t s = st ? st : c->stream;
+    const unsigned long long e = ++c->epoch;
+    const long long slice = ((long long)count + c->pv.nranks - 1) / c->pv.nranks;
+    const unsigned grid = (unsigned)std::min<long long>(256, std::max<long long>(1, (slice + 1023) / 1024));
+    hipLaunchKernelGGL(peer_reduce_kernel, dim3(grid), dim3(256), 0, s, c->pv, e, off, (long long)count, c->flags);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, c->pv, e, c->flags);
+    HIPCHK(hipGetLastError());
   } else if (c->host_reduce) {
     if (count > c->host_buf_count) return fail(NBMF_ERR_STATE, "internal: host exchange buffer too small");
     HIPCHK(hipMemcpyAsync(c->host_buf, p, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -409,7 +438,7 @@ int all_reduce_inplace(nbmf_ctx* c, double* p, size_t count, hipStream_t st = nu
   return NBMF_OK;
 }
 
-inline bool is_sharded(const nbmf_ctx* c) { return c->comm || c->host_reduce; }
+inline bool is_sharded(const nbmf_ctx* c) { return c->comm || c->host_reduce || c->peer; }
 
 // Binary path: the H-pass multiplies every entry of the padded mA x nA grid into the likelihood
 // product; a pad entry has Theta == 0 and is not an observed one, so it contributes exactly
@@ -507,8 +536,8 @@ int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false, i
   // axis 1: the prior sums were exchanged with the log-likelihood
   const bool prior_x = sh && c->shard_axis == 1;
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, ll_src, n_ll, pad,
-                     prior_x ? (const double*)(c->sbuf + 1) : (const double*)c->prior,
-                     loglik_only ? 0 : (prior_x ? 1 : c->n_prior_blocks),   // no prior term (and no 0 x NaN) in a pure log-likelihood
+                     prior_x ? (const double*)(c->sbuf + 1) : c->prior_src,
+                     loglik_only ? 0 : (prior_x ? 1 : c->n_prior_src),   // no prior term (and no 0 x NaN) in a pure log-likelihood
                      loglik_only ? 0.0 : c->alpha - 1.0, loglik_only ? 0.0 : c->beta - 1.0,
                      loglik_only ? -1.0 : c->n_obs_global, c->losses_d, t, tol, c->scal, c->flags);
   HIPCHK(hipGetLastError());
@@ -523,6 +552,8 @@ int enqueue_h_update(nbmf_ctx* c) {
                      (long long)c->nA, c->Hn, c->HT, c->HG, c->prior, c->k, c->KP, (long long)c->n, (long long)c->nA,
                      c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags);
   HIPCHK(hipGetLastError());
+  c->prior_src = c->prior;
+  c->n_prior_src = c->n_prior_blocks;
   return NBMF_OK;
 }
 
@@ -553,12 +584,73 @@ int enqueue_w_update(nbmf_ctx* c, const double* q, int chunks, double n_div, int
   return NBMF_OK;
 }
 
+// Rows of Y split, peer transport: the H-step exchange is this library's own reduce-scatter over xGMI with
+// the H-update fused in (each rank updates 1/R of the columns and broadcasts H', so the update is not
+// repeated R times and only K*N instead of 2*K*N doubles come back).  Order on the stream:
+//   H-pass -> slab reduction into the arena -> peer_h_kernel (H' staged in every arena, loglik total)
+//   -> loss + stop test of iteration it-1 -> peer_h_apply_kernel (skipped once the stop flag is up, so the
+//   factors stay those of iteration it-1, as in the single-GPU run) -> W-pass -> W-update.
+int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
+  const size_t per = (size_t)c->KP * c->nA;
+  PassArgs a{};
+  a.data = c->dataA;
+  a.mask = c->maskA;
+  a.LT = c->WT;
+  a.LG = c->WG;
+  a.RfT = c->HT;
+  a.out1 = c->slabH;
+  a.out2 = c->slabH + (size_t)c->chunksH * per;
+  a.lossbuf = c->lossbuf;
+  a.done = c->flags;
+  a.Rb = (int)(c->mA / 16);
+  a.Cb = (int)(c->nA / 16);
+  a.chunk_start = c->cstartH;
+  a.C_alloc = c->nA;
+  a.eps = c->eps;
+  {
+    EvScope ev(c, 0);
+    HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
+  }
+  const int n_loss = c->chunksH * (a.Cb / WG_WAVES);
+  double* X = c->arena;   // [P1 (KP x nA) | P2 (KP x nA) | loglik]
+  hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, (const double*)a.out1,
+                     (const double*)a.out2, c->chunksH, (long long)per, (long long)c->nA, 0LL, (long long)c->nA, c->KP, X,
+                     X + per, (const double*)c->lossbuf, n_loss, ll_pad_of(c), X + 2 * per, c->flags);
+  HIPCHK(hipGetLastError());
+  const unsigned long long e = ++c->epoch;
+  const unsigned long long hs = ++c->hseq;
+  const long long pr_stride = 2LL * c->n_prior_blocks;
+  const long long offPR_now = c->offPR + (long long)(hs & 1) * pr_stride;
+  double* ll_slot = c->scal + 4;
+  hipLaunchKernelGGL(peer_h_kernel, dim3((unsigned)((long long)c->KP * c->sl_wp / 256)), dim3(256), 0, c->stream, c->pv, e,
+                     (long long)per, (long long)(2 * per), c->offHX, offPR_now, c->sl_slot0, c->sl_c0, c->sl_wp,
+                     (const double*)c->Hn, c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0,
+                     c->eps, ll_slot, c->flags);
+  HIPCHK(hipGetLastError());
+  c->ll_ptr = ll_slot;
+  if (it > 0)
+    if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;   // reads the prior sums of the previous H-step
+  const unsigned grid = (unsigned)std::min<long long>(1024, std::max<long long>(1, (long long)per / 1024));
+  hipLaunchKernelGGL(peer_h_apply_kernel, dim3(grid), dim3(256), 0, c->stream, c->pv, e, c->offHX, c->Hn, c->HT, c->HG, c->KP,
+                     (long long)c->nA, c->flags);
+  HIPCHK(hipGetLastError());
+  c->prior_src = c->arena + offPR_now;
+  c->n_prior_src = c->n_prior_blocks;
+  PassArgs w = w_pass_args(c);
+  {
+    EvScope ev(c, 1);
+    HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, w, c->chunksW, c->stream));
+  }
+  return enqueue_w_update(c, c->slabW, c->chunksW, (double)c->n, c->projection);
+}
+
 // One whole iteration when the ROWS of Y are split over the ranks.  The exchange [P1 | P2 | loglik] is
 // cut into (at most) two column panels; panel 1's reduction + all-reduce + H-update run on stream2 while
 // stream 1 already updates panel 0 and sweeps the W-pass chunks that only read panel 0's columns of H'
 // (the W-pass is chunked over exactly that index).  With the host transport everything stays on one
 // stream (it synchronises anyway); the arithmetic is the same.
 int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
+  if (c->peer) return enqueue_iteration_rows_peer(c, it, tol);
   hipStream_t s0 = c->stream;
   const bool two_streams = c->npanel == 2 && c->comm && c->stream2;
   hipStream_t s1 = two_streams ? c->stream2 : s0;
@@ -604,6 +696,8 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
                        d1 + (size_t)c->KP * wp, 1, (size_t)0, wp, c0, c0, wp, c->Hn, c->HT, c->HG, c->prior + 2 * (size_t)blk0,
                        c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags);
     HIPCHK(hipGetLastError());
+    c->prior_src = c->prior;
+    c->n_prior_src = c->n_prior_blocks;
     return NBMF_OK;
   };
   // ---- panel 0 (+ loglik) on the main stream; the loss of iteration it-1 and its stop test
@@ -715,6 +809,49 @@ int setup_workspaces(nbmf_ctx* c) {
   return NBMF_OK;
 }
 
+// Drop whatever communicator is attached (the stream must be idle); the context is single-GPU again.
+void comm_release(nbmf_ctx* c, bool recount = false) {
+  // the column split replaced the per-row observed counts by their global sums: back to this shard's own
+  if (recount && is_sharded(c) && c->shard_axis == 1 && c->data_kind >= 0) {
+    hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
+                       c->data_kind, (long long)(c->nA / 16), (long long)c->m, c->rowcnt);
+    hipStreamSynchronize(c->stream);
+  }
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  c->comm = nullptr;
+  c->host_reduce = nullptr;
+  c->host_reduce_user = nullptr;
+  if (c->peer) {
+    c->Pbuf = c->Pbuf_own;
+    c->sbuf = c->sbuf_own;
+    c->Qbuf = c->Qbuf_own;
+    c->Pbuf_own = c->sbuf_own = c->Qbuf_own = nullptr;
+  }
+  for (void* q : c->peer_mapped) hipIpcCloseMemHandle(q);
+  c->peer_mapped.clear();
+  c->peer = false;
+  c->prior_src = c->prior;
+  c->n_prior_src = c->n_prior_blocks;
+  c->ll_ptr = nullptr;
+  c->nranks = 1;
+  c->rank = 0;
+  c->shard_axis = 0;
+  c->npanel = 1;
+  c->n_obs_global = c->n_obs;
+  c->n_div_global = (double)c->n;
+}
+
+// After a stream synchronisation: did a peer exchange give up waiting?
+int peer_check(nbmf_ctx* c) {
+  if (!c->peer) return NBMF_OK;
+  unsigned long long err = 0;
+  HIPCHK(hipMemcpy(&err, c->pflags + PF_ERR, sizeof err, hipMemcpyDeviceToHost));
+  if (err)
+    return fail(NBMF_ERR_COMM, "peer exchange %llu timed out on rank %d (a rank died, stalled for more than "
+                               "NBMF_PEER_TIMEOUT_MS, or ran a different sequence of calls); detach the communicator", err, c->rank);
+  return NBMF_OK;
+}
+
 int ready(nbmf_ctx* c) {
   if (!c) return fail(NBMF_ERR_ARG, "null context");
   if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "nbmf_upload has not been called");
@@ -795,6 +932,8 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
   HIPCHK(hipMalloc(&c->Pbuf, 2 * fh + 64));
   c->n_prior_blocks = (int)(((size_t)c->KP * c->nA + 255) / 256);
   HIPCHK(hipMalloc(&c->prior, sizeof(double) * 2 * (size_t)c->n_prior_blocks));
+  c->prior_src = c->prior;
+  c->n_prior_src = c->n_prior_blocks;
   HIPCHK(hipMalloc(&c->scal, sizeof(double) * 8));
   HIPCHK(hipMalloc(&c->sbuf, sizeof(double) * 8));
   HIPCHK(hipMalloc(&c->flags, sizeof(int) * 8));
@@ -813,8 +952,10 @@ int nbmf_destroy(nbmf_ctx* c) {
   if (!c) return NBMF_OK;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
-  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  comm_release(c);
   if (c->host_buf) hipHostFree(c->host_buf);
+  if (c->arena) hipFree(c->arena);
+  if (c->pflags) hipFree(c->pflags);
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
                   c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
                   c->sbuf, c->Qbuf, c->cstartH, c->cstartW};
@@ -981,7 +1122,7 @@ int nbmf_generate(nbmf_ctx* c, uint64_t seed, double density, double observed) {
   if (!c) return fail(NBMF_ERR_ARG, "null context");
   if (!(density >= 0.0 && density <= 1.0) || !(observed >= 0.0 && observed <= 1.0))
     return fail(NBMF_ERR_ARG, "density and observed must lie in [0, 1]");
-  if (c->comm || c->host_reduce) return fail(NBMF_ERR_STATE, "generate before attaching a communicator");
+  if (is_sharded(c)) return fail(NBMF_ERR_STATE, "generate before attaching a communicator");
   if (int rc = set_device(c)) return rc;
   for (void** p : {&c->dataA, &c->dataB, &c->maskA, &c->maskB}) {
     if (*p) hipFree(*p);
@@ -1041,6 +1182,8 @@ int nbmf_set_factors(nbmf_ctx* c, const double* W, const double* H) {
                      (long long)c->n, (long long)c->nA, c->eps);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
+  c->prior_src = c->prior;
+  c->n_prior_src = c->n_prior_blocks;
   c->have_factors = true;
   return NBMF_OK;
 }
@@ -1131,6 +1274,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
       HIPCHK(hipMemcpyAsync(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       if (c->timing) timing_collect(c);
+      if (int rc = peer_check(c)) return rc;
       host_done = fl[0];
     }
   }
@@ -1142,6 +1286,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   HIPCHK(hipMemcpyAsync(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->timing) timing_collect(c);
+  if (int rc = peer_check(c)) return rc;
   const int nit = fl[1];
   if (nit < 1 || nit > max_iter) return fail(NBMF_ERR_STATE, "internal: device reported n_iter=%d", nit);
   HIPCHK(hipMemcpy(losses, c->losses_d, sizeof(double) * (size_t)nit, hipMemcpyDeviceToHost));
@@ -1158,7 +1303,7 @@ int nbmf_w_only_steps(nbmf_ctx* c, int n_steps) {
     if (int rc = enqueue_w_step(c, NBMF_PROJ_NORMALIZE)) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->timing) timing_collect(c);
-  return NBMF_OK;
+  return peer_check(c);
 }
 
 int nbmf_loss(nbmf_ctx* c, double* loss) {
@@ -1170,12 +1315,14 @@ int nbmf_loss(nbmf_ctx* c, double* loss) {
   hipLaunchKernelGGL(prior_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Hn, c->prior, c->k, c->KP,
                      (long long)c->n, (long long)c->nA, c->eps);
   HIPCHK(hipGetLastError());
+  c->prior_src = c->prior;
+  c->n_prior_src = c->n_prior_blocks;
   if (int rc = enqueue_loglik_pass(c, 0)) return rc;
   if (int rc = enqueue_finalize(c, 0, 0.0)) return rc;
   HIPCHK(hipMemcpyAsync(loss, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->timing) timing_collect(c);
-  return NBMF_OK;
+  return peer_check(c);
 }
 
 int nbmf_loglik(nbmf_ctx* c, int clip_theta, double* loglik) {
@@ -1189,7 +1336,7 @@ int nbmf_loglik(nbmf_ctx* c, int clip_theta, double* loglik) {
   HIPCHK(hipMemcpyAsync(loglik, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->timing) timing_collect(c);
-  return NBMF_OK;
+  return peer_check(c);
 }
 
 int nbmf_loglik_strict(nbmf_ctx* c, double* loglik) {
@@ -1202,7 +1349,7 @@ int nbmf_loglik_strict(nbmf_ctx* c, double* loglik) {
   if (int rc = enqueue_finalize(c, 0, 0.0, /*loglik_only=*/true, /*strict=*/1)) return rc;   // no pad term, no prior
   HIPCHK(hipMemcpyAsync(loglik, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  return NBMF_OK;
+  return peer_check(c);
 }
 
 int nbmf_comm_unique_id(void* id128) {
@@ -1223,7 +1370,7 @@ static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   // with one rank, where there is nothing to hide); the break-even is an all-reduce of ~70 us, which cannot
   // be timed on a one-GPU box, so the default stays one panel.
   const char* ov = getenv("NBMF_OVERLAP");
-  c->npanel = (shard_axis == 0 && c->chunksW >= 2 && ov && atoi(ov) != 0) ? 2 : 1;
+  c->npanel = (shard_axis == 0 && !c->peer && c->chunksW >= 2 && ov && atoi(ov) != 0) ? 2 : 1;
   c->wsplit = c->npanel == 2 ? c->chunksW / 2 : c->chunksW;
   c->pc0[0] = 0;
   c->pc0[1] = c->npanel == 2 ? (long long)c->bW_host[c->wsplit] * 16 : c->nA;
@@ -1234,7 +1381,7 @@ static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   if (getenv("NBMF_DEBUG"))
     fprintf(stderr, "[nbmf] rank %d/%d axis %d: %d exchange panel(s), columns split at %lld of %lld, W-pass chunks %d + %d, %s\n",
             rank, nranks, shard_axis, c->npanel, c->pc0[1], (long long)c->nA, c->wsplit, c->chunksW - c->wsplit,
-            c->comm ? "RCCL" : "host transport");
+            c->comm ? "RCCL" : c->peer ? "peer (xGMI)" : "host transport");
   if (c->npanel == 2 && c->comm && !c->stream2) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->evH, hipEventDisableTiming));
@@ -1253,7 +1400,13 @@ static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   c->n_div_global = (shard_axis == 1) ? h[1] : (double)c->n;
   if (shard_axis == 1) {
     HIPCHK(hipMemsetAsync(c->rowcnt + c->m, 0, sizeof(double) * (size_t)(c->mA - c->m), c->stream));
-    if (int rc = all_reduce_inplace(c, c->rowcnt, (size_t)c->mA)) return rc;
+    if (c->peer) {   // the peer exchange works on the arena only
+      HIPCHK(hipMemcpyAsync(c->arena, c->rowcnt, sizeof(double) * (size_t)c->mA, hipMemcpyDeviceToDevice, c->stream));
+      if (int rc = all_reduce_inplace(c, c->arena, (size_t)c->mA)) return rc;
+      HIPCHK(hipMemcpyAsync(c->rowcnt, c->arena, sizeof(double) * (size_t)c->mA, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+      if (int rc = all_reduce_inplace(c, c->rowcnt, (size_t)c->mA)) return rc;
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   return NBMF_OK;
@@ -1263,7 +1416,7 @@ static int comm_check_args(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(NBMF_ERR_ARG, "bad rank %d / nranks %d", rank, nranks);
   if (shard_axis != 0 && shard_axis != 1) return fail(NBMF_ERR_ARG, "shard_axis must be 0 (rows of Y) or 1 (columns of Y)");
   if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "call nbmf_upload before attaching a communicator (global counts are reduced there)");
-  if (c->comm || c->host_reduce) return fail(NBMF_ERR_STATE, "a communicator is already attached");
+  if (is_sharded(c)) return fail(NBMF_ERR_STATE, "a communicator is already attached (nbmf_comm_detach first)");
   return NBMF_OK;
 }
 
@@ -1290,6 +1443,144 @@ int nbmf_comm_init_host(nbmf_ctx* c, nbmf_host_allreduce_fn fn, void* user, int 
   c->host_reduce = fn;
   c->host_reduce_user = user;
   return comm_finish_init(c, nranks, rank, shard_axis);
+}
+
+int nbmf_comm_detach(nbmf_ctx* c) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (int rc = set_device(c)) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));
+  comm_release(c, /*recount=*/true);
+  return NBMF_OK;
+}
+
+// Arena layout in doubles (same on every rank for a given axis, because the unsplit extent is):
+//   axis 0   X = [P1 | P2 | loglik .. 8]   HX = H' staging [KP][nA]   PR = 2 x prior partial pairs   SC = 64 scalars
+//   axis 1   X = [Q (KP x mA) .. 8]        SC = 64 scalars
+static void peer_layout(nbmf_ctx* c, int axis) {
+  const long long fh = (long long)c->KP * c->nA, fw = (long long)c->KP * c->mA;
+  if (axis == 0) {
+    c->x_doubles = 2 * fh + 8;
+    c->offHX = c->x_doubles;
+    c->offPR = c->offHX + fh;
+    c->offSC = c->offPR + 4LL * c->n_prior_blocks;
+  } else {
+    c->x_doubles = fw + 8;
+    c->offHX = c->offPR = c->offSC = c->x_doubles;
+  }
+}
+
+int nbmf_peer_export(nbmf_ctx* c, int shard_axis, void* handle) {
+  if (!c || !handle) return fail(NBMF_ERR_ARG, "null argument");
+  if (shard_axis != 0 && shard_axis != 1) return fail(NBMF_ERR_ARG, "shard_axis must be 0 or 1");
+  if (is_sharded(c)) return fail(NBMF_ERR_STATE, "a communicator is already attached (nbmf_comm_detach first)");
+  if (int rc = set_device(c)) return rc;
+  static_assert(2 * sizeof(hipIpcMemHandle_t) <= NBMF_PEER_HANDLE_BYTES, "handle block too small");
+  // a fresh arena and flag block every time: epochs restart at zero on all ranks together
+  if (c->arena) HIPCHK(hipFree(c->arena));
+  if (c->pflags) HIPCHK(hipFree(c->pflags));
+  c->arena = nullptr;
+  c->pflags = nullptr;
+  peer_layout(c, shard_axis);
+  c->arena_doubles = (size_t)(c->offSC + 64);
+  c->arena_axis = shard_axis;
+  HIPCHK(hipExtMallocWithFlags((void**)&c->arena, c->arena_doubles * sizeof(double), hipDeviceMallocUncached));
+  HIPCHK(hipExtMallocWithFlags((void**)&c->pflags, PF_WORDS * sizeof(unsigned long long), hipDeviceMallocUncached));
+  HIPCHK(hipMemset(c->arena, 0, c->arena_doubles * sizeof(double)));
+  HIPCHK(hipMemset(c->pflags, 0, PF_WORDS * sizeof(unsigned long long)));
+  HIPCHK(hipDeviceSynchronize());
+  c->epoch = 0;
+  c->hseq = 0;
+  hipIpcMemHandle_t h[2];
+  HIPCHK(hipIpcGetMemHandle(&h[0], c->arena));
+  HIPCHK(hipIpcGetMemHandle(&h[1], c->pflags));
+  memset(handle, 0, NBMF_PEER_HANDLE_BYTES);
+  memcpy(handle, h, sizeof h);
+  return NBMF_OK;
+}
+
+int nbmf_comm_init_peer(nbmf_ctx* c, const void* handles, int nranks, int rank, int shard_axis) {
+  if (!c || !handles) return fail(NBMF_ERR_ARG, "null argument");
+  if (int rc = comm_check_args(c, nranks, rank, shard_axis)) return rc;
+  if (nranks > PEER_MAX_RANKS) return fail(NBMF_ERR_ARG, "the peer transport supports at most %d ranks", PEER_MAX_RANKS);
+  if (!c->arena || c->arena_axis != shard_axis)
+    return fail(NBMF_ERR_STATE, "call nbmf_peer_export(ctx, %d, ...) on every rank first", shard_axis);
+  if (shard_axis == 0 && c->nA / 16 < nranks) return fail(NBMF_ERR_ARG, "too few columns to slice the H-step over %d ranks", nranks);
+  if (int rc = set_device(c)) return rc;
+  PeerView pv{};
+  pv.nranks = nranks;
+  pv.rank = rank;
+  double ms = 30000.0;
+  if (const char* e = getenv("NBMF_PEER_TIMEOUT_MS")) ms = std::max(1.0, atof(e));
+  pv.timeout = (unsigned long long)(ms * 1e5);   // wall_clock64 ticks at 100 MHz
+  struct Undo {   // any failure below leaves the context unattached
+    nbmf_ctx* c;
+    bool armed = true;
+    ~Undo() {
+      if (armed) {
+        hipStreamSynchronize(c->stream);
+        comm_release(c, /*recount=*/true);
+      }
+    }
+  } undo{c};
+  for (int j = 0; j < nranks; ++j) {
+    if (j == rank) {
+      pv.arena[j] = c->arena;
+      pv.flag[j] = c->pflags;
+      continue;
+    }
+    hipIpcMemHandle_t h[2];
+    memcpy(h, (const char*)handles + (size_t)j * NBMF_PEER_HANDLE_BYTES, sizeof h);
+    void *a = nullptr, *f = nullptr;
+    HIPCHK(hipIpcOpenMemHandle(&a, h[0], hipIpcMemLazyEnablePeerAccess));
+    c->peer_mapped.push_back(a);
+    HIPCHK(hipIpcOpenMemHandle(&f, h[1], hipIpcMemLazyEnablePeerAccess));
+    c->peer_mapped.push_back(f);
+    pv.arena[j] = (double*)a;
+    pv.flag[j] = (unsigned long long*)f;
+  }
+  c->pv = pv;
+  c->peer = true;
+  c->Pbuf_own = c->Pbuf;
+  c->sbuf_own = c->sbuf;
+  c->Qbuf_own = c->Qbuf;
+  c->Pbuf = c->arena;
+  c->Qbuf = c->arena;
+  c->sbuf = c->arena + c->offSC;
+  if (shard_axis == 0) {
+    // column slices of the fused H-step, in 16-column blocks; workgroup w of rank r owns prior slot slot0_r + w
+    const long long nb = c->nA / 16;
+    const long long b0 = nb * rank / nranks, b1 = nb * (rank + 1) / nranks;
+    c->sl_c0 = 16 * b0;
+    c->sl_wp = 16 * (b1 - b0);
+    c->sl_slot0 = (int)((long long)c->KP * c->sl_c0 / 256);
+  }
+  // Known-answer exchange before anything depends on the transport: rank r contributes (r+1)*(i%1021+1)+t,
+  // all exact in binary64, twice with different data (also the first rendezvous of the ranks).
+  {
+    const size_t cnt = (size_t)std::min<long long>(c->x_doubles, 1 << 20);
+    std::vector<double> h(cnt);
+    const unsigned long long full = c->pv.timeout;
+    c->pv.timeout = std::min<unsigned long long>(full, 10ull * 100000000ull);
+    for (int t = 0; t < 2; ++t) {
+      for (size_t i = 0; i < cnt; ++i) h[i] = (double)(rank + 1) * (double)(i % 1021 + 1) + t;
+      HIPCHK(hipMemcpyAsync(c->arena, h.data(), cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      if (int rc = all_reduce_inplace(c, c->arena, cnt)) return rc;
+      HIPCHK(hipMemcpyAsync(h.data(), c->arena, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (int rc = peer_check(c)) return rc;
+      const double tri = 0.5 * nranks * (nranks + 1);
+      for (size_t i = 0; i < cnt; ++i)
+        if (h[i] != tri * (double)(i % 1021 + 1) + (double)t * nranks)
+          return fail(NBMF_ERR_COMM, "peer transport self-test failed at element %zu (got %.17g)", i, h[i]);
+    }
+    c->pv.timeout = full;
+    HIPCHK(hipMemsetAsync(c->arena, 0, cnt * sizeof(double), c->stream));
+  }
+  if (int rc = comm_finish_init(c, nranks, rank, shard_axis)) return rc;
+  if (int rc = peer_check(c)) return rc;
+  undo.armed = false;
+  return NBMF_OK;
 }
 
 int nbmf_timing_enable(nbmf_ctx* c, int enable) {

@@ -1,0 +1,195 @@
+"""Peer (xGMI) transport on the GPU box: several processes share the one MI355X and map each other's
+exchange arenas through HIP IPC, so the library's own exchange kernels (reduce-scatter fused with the
+H-update, two-shot all-reduce, bounded waits) run exactly as they would across GPUs -- only the wires are
+missing.  Checked against the single-process HIP run, the host-transport run and the CPU oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    g = np.random.default_rng(21)
+    M, N, K = 700, 333, 24
+    Y = (g.random((M, N)) < 0.3).astype(np.float64)
+    mask = g.random((M, N)) < 0.9
+    return M, N, K, Y, mask
+
+
+def _setup(rank, world, port):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.setdefault("NBMF_PEER_TIMEOUT_MS", "20000")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    return dist
+
+
+def _worker_rows(rank, world, port, q):
+    dist = _setup(rank, world, port)
+    from nbmf_mm_amd import _dist
+    try:
+        M, N, K, Y, mask = _problem()
+        r0, r1 = _dist.shard_bounds(M, world, rank)
+        out = {}
+        for name, kw in [("tol0", dict(max_iter=30, tol=0)), ("stop", dict(max_iter=400, tol=1e-4))]:
+            out[name] = _dist.fit_row_sharded(Y[r0:r1], M, r0, K, dist, alpha=1.2, beta=1.3, mask_local=mask[r0:r1],
+                                              random_state=5, device=0, transport="peer", **kw)
+        q.put((rank, r0, r1, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(target, world, *extra):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_shards_peer_transport(world):
+    """Fused reduce-scatter + H-update + broadcast: factors and loss curve of the single-process run, the
+    replicated factor bitwise equal on all ranks, and the stop rule firing at the same iteration."""
+    from nbmf_mm_amd import nbmf_mm_solver
+    from oracle import nbmf_oracle as orc
+    res = _run(_worker_rows, world)
+    M, N, K, Y, mask = _problem()
+    W1, H1, l1, _, n1 = nbmf_mm_solver(Y, K, max_iter=30, tol=0, alpha=1.2, beta=1.3, mask=mask, random_state=5)
+    Wr, Hr, lr, _, _ = orc.solve(Y, K, max_iter=30, tol=0, alpha=1.2, beta=1.3, mask=mask, random_state=5)
+    W = np.concatenate([r[3]["tol0"][0] for r in res], axis=0)
+    for ref_W, ref_H, ref_l, tol in [(W1, H1, l1, 1e-12), (Wr, Hr, lr, 1e-9)]:
+        np.testing.assert_allclose(W, ref_W, rtol=0, atol=tol)
+        np.testing.assert_allclose(res[0][3]["tol0"][1], ref_H, rtol=0, atol=tol)
+        np.testing.assert_allclose(res[0][3]["tol0"][2], ref_l, rtol=1e-10, atol=0)
+    for r in res[1:]:
+        np.testing.assert_array_equal(r[3]["tol0"][1], res[0][3]["tol0"][1])
+        np.testing.assert_array_equal(r[3]["tol0"][2], res[0][3]["tol0"][2])
+    W2, H2, l2, _, n2 = nbmf_mm_solver(Y, K, max_iter=400, tol=1e-4, alpha=1.2, beta=1.3, mask=mask, random_state=5)
+    assert 5 < n2 < 400
+    for r in res:
+        assert r[3]["stop"][3] == n2
+        np.testing.assert_allclose(r[3]["stop"][1], H2, rtol=0, atol=1e-11)      # factors of iteration n2, not n2+1
+        np.testing.assert_allclose(r[3]["stop"][2], l2, rtol=1e-10, atol=0)
+    np.testing.assert_allclose(np.concatenate([r[3]["stop"][0] for r in res], axis=0), W2, rtol=0, atol=1e-11)
+
+
+def _worker_axis1(rank, world, port, q):
+    dist = _setup(rank, world, port)
+    from nbmf_mm_amd import _dist, _hip
+    try:
+        M, N, K, Y, mask = _problem()
+        V, Vmask = Y[:300, :], mask[:300, :]
+        out = {}
+        r0, r1 = _dist.shard_bounds(V.shape[0], world, rank)
+        out["db_rows"] = (r0, r1) + _dist.fit_sharded(V[r0:r1], V.shape, r0, 9, dist, orientation="dir-beta", shard="rows",
+                                                     max_iter=25, tol=0, mask_local=Vmask[r0:r1], random_state=4,
+                                                     device=0, transport="peer")
+        c0, c1 = _dist.shard_bounds(V.shape[1], world, rank)
+        out["bd_cols"] = (c0, c1) + _dist.fit_sharded(V[:, c0:c1], V.shape, c0, 9, dist, orientation="beta-dir", shard="cols",
+                                                     max_iter=200, tol=1e-4, mask_local=Vmask[:, c0:c1], random_state=4,
+                                                     projection="duchi", device=0, transport="peer")
+        # evaluation sweeps on a sharded context, and detach -> re-attach with another transport
+        Wg, Hg = _dist.global_init(V.shape[0], V.shape[1], 9, random_state=4)
+        with _hip.Context(V.shape[0], c1 - c0, 9) as ctx:
+            ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_DUCHI)
+            ctx.upload(V[:, c0:c1], mask=Vmask[:, c0:c1])
+            ctx.set_factors(Wg, np.ascontiguousarray(Hg[:, c0:c1]))
+            used = _dist.attach_comm(ctx, dist, "auto", shard_axis=1)
+            a = (used, ctx.loss(), ctx.loglik(), ctx.n_obs())
+            la, _ = ctx.run(5, 0.0)
+            ctx.comm_detach()
+            ctx.set_factors(Wg, np.ascontiguousarray(Hg[:, c0:c1]))
+            used2 = _dist.attach_comm(ctx, dist, "host", shard_axis=1)
+            b = (used2, ctx.loss(), ctx.loglik(), ctx.n_obs())
+            lb, _ = ctx.run(5, 0.0)
+        out["eval"] = (a, b, la, lb)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_column_split_peer_transport():
+    from nbmf_mm_amd import nbmf_mm_solver
+    res = [o for _, o in _run(_worker_axis1, 2)]
+    M, N, K, Y, mask = _problem()
+    V, Vmask = Y[:300, :], mask[:300, :]
+    W1, H1, l1, _, _ = nbmf_mm_solver(V, 9, max_iter=25, tol=0, mask=Vmask, random_state=4, orientation="dir-beta")
+    W = np.concatenate([r["db_rows"][2] for r in res], axis=0)
+    np.testing.assert_allclose(W, W1, rtol=0, atol=1e-12)
+    for r in res:
+        np.testing.assert_allclose(r["db_rows"][3], H1, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(r["db_rows"][4], l1, rtol=1e-10, atol=0)
+    np.testing.assert_array_equal(res[0]["db_rows"][3], res[1]["db_rows"][3])
+    W2, H2, l2, _, n2 = nbmf_mm_solver(V, 9, max_iter=200, tol=1e-4, mask=Vmask, random_state=4, projection="duchi")
+    Hc = np.concatenate([r["bd_cols"][3] for r in res], axis=1)
+    np.testing.assert_allclose(Hc, H2, rtol=0, atol=1e-11)
+    for r in res:
+        assert r["bd_cols"][5] == n2
+        np.testing.assert_allclose(r["bd_cols"][2], W2, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(r["bd_cols"][4], l2, rtol=1e-10, atol=0)
+    assert sum(r["eval"][0][3] for r in res) == float(np.count_nonzero(Vmask))
+    for r in res:
+        a, b, la, lb = r["eval"]
+        assert a[0] == "peer" and b[0] == "host"             # "auto" picks the peer transport when it works
+        assert a[3] == b[3]                                  # this shard's own observed count
+        np.testing.assert_allclose(a[1:3], b[1:3], rtol=1e-13)
+        np.testing.assert_allclose(la, lb, rtol=1e-12)       # Duchi after detach: row counts were restored, not doubled
+
+
+def _worker_absent_peer(rank, world, port, q):
+    os.environ["NBMF_PEER_TIMEOUT_MS"] = "1500"
+    dist = _setup(rank, world, port)
+    from nbmf_mm_amd import _dist, _hip
+    import time
+    try:
+        M, N, K, Y, mask = _problem()
+        r0, r1 = _dist.shard_bounds(M, world, rank)
+        W, H = _dist.global_init(M, N, K, random_state=5)
+        with _hip.Context(r1 - r0, N, K) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            ctx.upload(Y[r0:r1], mask=mask[r0:r1])
+            ctx.set_factors(np.ascontiguousarray(W[:, r0:r1]), H)
+            table = [None] * world
+            dist.all_gather_object(table, ctx.peer_export(0))
+            t0 = time.perf_counter()
+            msg = None
+            if rank == 0:                       # rank 1 never attaches: rank 0 must give up, not hang
+                try:
+                    ctx.comm_init_peer(b"".join(table), world, rank, 0)
+                except _hip.NBMFHipError as e:
+                    msg = str(e)
+            dt = time.perf_counter() - t0
+            # the context is unattached again and still works on its own shard
+            losses, n_iter = ctx.run(3, 0.0)
+            q.put((rank, msg, dt, n_iter))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_missing_rank_times_out_instead_of_hanging():
+    res = _run(_worker_absent_peer, 2)
+    assert res[0][1] is not None and "timed out" in res[0][1]
+    assert res[0][2] < 15.0
+    assert res[0][3] == res[1][3] == 3
