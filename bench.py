@@ -111,7 +111,8 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="row-split exchange in two panels, second one overlapped with compute (sets NBMF_OVERLAP=1)")
     ap.add_argument("--force-comm", action="store_true",
-                    help="attach a 1-rank RCCL communicator even with --gpus 1 (rehearses the sharded code path)")
+                    help="attach a 1-rank communicator (RCCL, or the peer transport with --transport peer) even with --gpus 1: "
+                         "the sharded code path and its per-iteration overhead, minus the wires")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -159,8 +160,12 @@ def main():
     if world > 1:
         transport = _dist.attach_comm(ctx, dist, args.transport)
     elif args.force_comm:
-        ctx.comm_init(_hip.comm_unique_id(), 1, 0)
-        transport = "rccl(1 rank)"
+        if args.transport == "peer":
+            ctx.comm_init_peer(ctx.peer_export(0), 1, 0)
+            transport = "peer(1 rank)"
+        else:
+            ctx.comm_init(_hip.comm_unique_id(), 1, 0)
+            transport = "rccl(1 rank)"
 
     dev = 0 if args.share_gpu else local_rank
     if torch.cuda.is_available():

@@ -220,7 +220,6 @@ struct nbmf_ctx {
   unsigned long long epoch = 0, hseq = 0;
   long long offHX = 0, offPR = 0, offSC = 0, x_doubles = 0;
   long long sl_c0 = 0, sl_wp = 0;   // axis 0: the column slice of H this rank updates
-  int sl_slot0 = 0;
   double *Pbuf_own = nullptr, *sbuf_own = nullptr, *Qbuf_own = nullptr;   // the private buffers while the arena stands in
   // timing
   bool timing = false;
@@ -422,7 +421,7 @@ int all_reduce_inplace(nbmf_ctx* c, double* p, size_t count, hipStream_t st = nu
     hipStream_t s = st ? st : c->stream;
     const unsigned long long e = ++c->epoch;
     const long long slice = ((long long)count + c->pv.nranks - 1) / c->pv.nranks;
-    const unsigned grid = (unsigned)std::min<long long>(256, std::max<long long>(1, (slice + 1023) / 1024));
+    const unsigned grid = (unsigned)std::min<long long>(128, std::max<long long>(1, (slice + 1023) / 1024));
     hipLaunchKernelGGL(peer_reduce_kernel, dim3(grid), dim3(256), 0, s, c->pv, e, off, (long long)count, c->flags);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, c->pv, e, c->flags);
@@ -619,23 +618,23 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   HIPCHK(hipGetLastError());
   const unsigned long long e = ++c->epoch;
   const unsigned long long hs = ++c->hseq;
-  const long long pr_stride = 2LL * c->n_prior_blocks;
-  const long long offPR_now = c->offPR + (long long)(hs & 1) * pr_stride;
+  const int n_slots = PEER_H_WGS * c->pv.nranks;
+  const long long offPR_now = c->offPR + (long long)(hs & 1) * 2 * PEER_H_WGS * PEER_MAX_RANKS;
   double* ll_slot = c->scal + 4;
-  hipLaunchKernelGGL(peer_h_kernel, dim3((unsigned)((long long)c->KP * c->sl_wp / 256)), dim3(256), 0, c->stream, c->pv, e,
-                     (long long)per, (long long)(2 * per), c->offHX, offPR_now, c->sl_slot0, c->sl_c0, c->sl_wp,
-                     (const double*)c->Hn, c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0,
-                     c->eps, ll_slot, c->flags);
+  hipLaunchKernelGGL(peer_h_kernel, dim3(PEER_H_WGS), dim3(256), 0, c->stream, c->pv, e, (long long)per, (long long)(2 * per),
+                     c->offHX, offPR_now, PEER_H_WGS * c->pv.rank, c->sl_c0, c->sl_wp, (const double*)c->Hn, c->k, c->KP,
+                     (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, ll_slot, c->flags);
   HIPCHK(hipGetLastError());
   c->ll_ptr = ll_slot;
   if (it > 0)
     if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;   // reads the prior sums of the previous H-step
-  const unsigned grid = (unsigned)std::min<long long>(1024, std::max<long long>(1, (long long)per / 1024));
-  hipLaunchKernelGGL(peer_h_apply_kernel, dim3(grid), dim3(256), 0, c->stream, c->pv, e, c->offHX, c->Hn, c->HT, c->HG, c->KP,
-                     (long long)c->nA, c->flags);
+  hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, c->stream, c->pv, e, c->flags);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(peer_h_apply_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream,
+                     (const double*)(c->arena + c->offHX), c->Hn, c->HT, c->HG, c->KP, (long long)c->nA, c->flags);
   HIPCHK(hipGetLastError());
   c->prior_src = c->arena + offPR_now;
-  c->n_prior_src = c->n_prior_blocks;
+  c->n_prior_src = n_slots;
   PassArgs w = w_pass_args(c);
   {
     EvScope ev(c, 1);
@@ -1463,7 +1462,7 @@ static void peer_layout(nbmf_ctx* c, int axis) {
     c->x_doubles = 2 * fh + 8;
     c->offHX = c->x_doubles;
     c->offPR = c->offHX + fh;
-    c->offSC = c->offPR + 4LL * c->n_prior_blocks;
+    c->offSC = c->offPR + 2LL * 2 * PEER_H_WGS * PEER_MAX_RANKS;
   } else {
     c->x_doubles = fw + 8;
     c->offHX = c->offPR = c->offSC = c->x_doubles;
@@ -1548,12 +1547,11 @@ int nbmf_comm_init_peer(nbmf_ctx* c, const void* handles, int nranks, int rank, 
   c->Qbuf = c->arena;
   c->sbuf = c->arena + c->offSC;
   if (shard_axis == 0) {
-    // column slices of the fused H-step, in 16-column blocks; workgroup w of rank r owns prior slot slot0_r + w
+    // column slices of the fused H-step, in 16-column blocks
     const long long nb = c->nA / 16;
     const long long b0 = nb * rank / nranks, b1 = nb * (rank + 1) / nranks;
     c->sl_c0 = 16 * b0;
     c->sl_wp = 16 * (b1 - b0);
-    c->sl_slot0 = (int)((long long)c->KP * c->sl_c0 / 256);
   }
   // Known-answer exchange before anything depends on the transport: rank r contributes (r+1)*(i%1021+1)+t,
   // all exact in binary64, twice with different data (also the first rendezvous of the ranks).
