@@ -109,3 +109,89 @@ def test_global_init_matches_reference_rule():
     H0 = np.random.uniform(0.1, 0.9, (4, 30))
     np.testing.assert_array_equal(H, H0)
     np.testing.assert_array_equal(W, W0.T / W0.T.sum(axis=0, keepdims=True))
+
+
+class _StubCtx:
+    """Stands in for a _hip.Context in the transport-negotiation test: records the calls attach_comm makes and
+    fails where told to."""
+
+    def __init__(self, fail):
+        self.fail, self.calls = set(fail), []
+
+    def peer_export(self, axis):
+        self.calls.append("export")
+        if "export" in self.fail:
+            from nbmf_mm_amd import _hip
+            raise _hip.NBMFHipError("no IPC here")
+        return bytes(128)
+
+    def comm_init_peer(self, handles, world, rank, axis):
+        self.calls.append("peer")
+        assert len(handles) == 128 * world
+        if "peer" in self.fail:
+            from nbmf_mm_amd import _hip
+            raise _hip.NBMFHipError("peer transport self-test failed")
+
+    def comm_init(self, uid, world, rank, axis):
+        self.calls.append("rccl")
+        if "rccl" in self.fail:
+            from nbmf_mm_amd import _hip
+            raise _hip.NBMFHipError("ncclCommInitRank failed")
+
+    def comm_init_host(self, fn, world, rank, axis):
+        self.calls.append("host")
+
+    def comm_detach(self):
+        self.calls.append("detach")
+
+
+def _worker_negotiate(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    from nbmf_mm_amd import _dist, _hip
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    _hip.comm_unique_id = lambda: bytes(128)          # no librccl call on the CPU box
+    try:
+        out = {}
+        # everything works: peer wins, nothing else is touched
+        c = _StubCtx([])
+        out["ok"] = (_dist.attach_comm(c, dist, "auto"), c.calls)
+        # the peer attach fails on rank 1 only: rank 0 must detach and BOTH move on to RCCL
+        c = _StubCtx(["peer"] if rank == 1 else [])
+        out["peer_fails_on_1"] = (_dist.attach_comm(c, dist, "auto"), c.calls)
+        # no IPC on rank 0, RCCL init fails on rank 1: both end on the host transport
+        c = _StubCtx((["export"] if rank == 0 else []) + (["rccl"] if rank == 1 else []))
+        out["down_to_host"] = (_dist.attach_comm(c, dist, "auto"), c.calls)
+        # an explicit transport does not fall back: every rank raises
+        c = _StubCtx(["peer"] if rank == 0 else [])
+        try:
+            _dist.attach_comm(c, dist, "peer")
+            out["explicit"] = ("no error", c.calls)
+        except _hip.NBMFHipError as e:
+            out["explicit"] = ("raised", c.calls)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transport_negotiation_never_splits_the_job():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_negotiate, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [o for _, o in sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert [r["ok"] for r in res] == [("peer", ["export", "peer"])] * 2
+    assert res[0]["peer_fails_on_1"] == ("rccl", ["export", "peer", "detach", "rccl"])
+    assert res[1]["peer_fails_on_1"] == ("rccl", ["export", "peer", "rccl"])
+    assert res[0]["down_to_host"] == ("host", ["export", "rccl", "detach", "host"])
+    assert res[1]["down_to_host"] == ("host", ["export", "rccl", "host"])
+    assert res[0]["explicit"] == ("raised", ["export", "peer"])
+    assert res[1]["explicit"] == ("raised", ["export", "peer", "detach"])
