@@ -141,6 +141,52 @@ __device__ __forceinline__ double log_fast(double x) {
   return dk * 6.93147180369123816490e-01 - ((hfsq - __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
 }
 
+// Per-lane selects on a 64-bit wave mask, written out because the pass kernels are VALU-issue bound next to
+// their MFMAs: a byte test is ONE SDWA compare (hipcc otherwise emits v_and + v_cmp), a double select is two
+// v_cndmask_b32 (with the zero / negated alternative folded into the operand).
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ lanemask_t byte_set(uint32_t x, int byte) {   // lanes whose byte `byte` of x is non-zero
+  lanemask_t m;
+  const uint32_t zero = 0u;
+  switch (byte) {
+    case 0: __asm__("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD" : "=s"(m) : "v"(x), "v"(zero)); break;
+    case 1: __asm__("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD" : "=s"(m) : "v"(x), "v"(zero)); break;
+    case 2: __asm__("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD" : "=s"(m) : "v"(x), "v"(zero)); break;
+    default: __asm__("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:DWORD" : "=s"(m) : "v"(x), "v"(zero)); break;
+  }
+  return m;
+}
+__device__ __forceinline__ double sel64(lanemask_t m, double a, double b) {   // m ? a : b
+  const uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+  const uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+  uint32_t lo, hi;
+  __asm__("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(blo), "v"(alo), "s"(m));
+  __asm__("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(bhi), "v"(ahi), "s"(m));
+  return mk_double(lo, hi);
+}
+__device__ __forceinline__ double sel64_or0(lanemask_t m, double a) {   // m ? a : 0
+  const uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+  uint32_t lo, hi;
+  __asm__("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"(alo), "s"(m));
+  __asm__("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(ahi), "s"(m));
+  return mk_double(lo, hi);
+}
+__device__ __forceinline__ double sel64_0or(lanemask_t m, double b) {   // m ? 0 : b
+  const uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+  uint32_t lo, hi;
+  __asm__("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(lo) : "v"(blo), "s"(m));
+  __asm__("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(hi) : "v"(bhi), "s"(m));
+  return mk_double(lo, hi);
+}
+__device__ __forceinline__ double sel64_neg(lanemask_t m, double a, double b) {   // m ? a : -b
+  const uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+  const uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+  uint32_t lo, hi;
+  __asm__("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(blo), "v"(alo), "s"(m));
+  __asm__("v_cndmask_b32_e64 %0, -%1, %2, %3" : "=v"(hi) : "v"(bhi), "v"(ahi), "s"(m));   // the float negate modifier flips bit 31
+  return mk_double(lo, hi);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
   // fixed butterfly order -> bitwise reproducible
 #pragma unroll
