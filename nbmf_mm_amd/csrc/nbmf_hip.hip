@@ -49,6 +49,9 @@
 #ifndef NBMF_STAGE_HALF
 #define NBMF_STAGE_HALF 1   // 16 KiB stages (3 workgroups per CU at K <= 64); 0 = 32 KiB stages
 #endif
+#ifndef NBMF_SADDR
+#define NBMF_SADDR 1   // stage/code loads addressed as scalar base + lane offset (see STAGE_DMA)
+#endif
 #ifndef NBMF_LDS_DMA
 #define NBMF_LDS_DMA 1   // stage the factor panels with global_load_lds (LDS-DMA); 0 = through registers
 #endif
