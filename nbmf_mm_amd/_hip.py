@@ -23,7 +23,7 @@ NBMF_ERR_COMM = -5
 MASK_NONE, MASK_F64, MASK_U8 = 0, 1, 2
 PROJ_NORMALIZE, PROJ_DUCHI = 0, 1
 FLAG_BINARY_PATH = 1
-MAX_K = 128
+MAX_K = 512
 PEER_HANDLE_BYTES = 128
 
 #: every symbol include/nbmf_hip.h declares (checked by tests/test_abi.py)

@@ -86,11 +86,12 @@ inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 enum { DATA_BIN = 0, DATA_F64 = 1, DATA_F64M = 2 };
-enum { MODE_H = 0, MODE_W = 1, MODE_L = 2 };
+enum { MODE_H = 0, MODE_W = 1, MODE_L = 2, MODE_T = 3 };
 
 // code bits of the binary path
 enum : unsigned { CB_YM = 1u, CB_ZOBS = 2u, CB_VALID = 4u };
 
+constexpr int SLICE_K = 128;      // n_components beyond this run as slices of SLICE_K components
 constexpr int PAD = 128;          // m and n are padded to multiples of 128 (8 row blocks, 8 strips)
 #ifndef NBMF_WG_WAVES
 #define NBMF_WG_WAVES 4
@@ -212,6 +213,8 @@ struct nbmf_ctx {
   hipStream_t stream = nullptr;
   int64_t m = 0, n = 0, mA = 0, nA = 0;
   int k = 0, KP = 0, KB = 0;
+  int KS = 1;               // slices of SLICE_K components (n_components > 128); KP = SLICE_K * KS then
+  double* theta = nullptr;  // KS > 1: Theta in tile order, shared by the slices' sweeps
   int data_kind = -1;   // -1 = nothing uploaded
   void *dataA = nullptr, *dataB = nullptr, *maskA = nullptr, *maskB = nullptr;
   double n_obs = 0, n_obs_global = 0;
@@ -325,16 +328,30 @@ constexpr int kNcclSum = 0;       // ncclSum
   } while (0)
 
 // ---- pass launch ----------------------------------------------------------------------------
-template <int KB, int DATA, int MODE>
+template <int KB, int DATA, int MODE, int TH = 0>
 hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
   dim3 grid(a.Cb / WG_WAVES, chunks);
   constexpr int lds_bytes = (NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES;
   if (lds_bytes > 65536) {
-    hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
+  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
   return hipGetLastError();
+}
+
+// n_components > 128: the sweep of one slice with Theta read from memory (TH = 1), and the Theta sweep itself
+template <int MODE>
+hipError_t launch_pass_slice(int data_kind, const PassArgs& a, int chunks, hipStream_t st) {
+  switch (data_kind) {
+    case DATA_BIN: return launch_pass_t<8, DATA_BIN, MODE, 1>(a, chunks, st);
+    case DATA_F64: return launch_pass_t<8, DATA_F64, MODE, 1>(a, chunks, st);
+    case DATA_F64M: return launch_pass_t<8, DATA_F64M, MODE, 1>(a, chunks, st);
+  }
+  return hipErrorInvalidValue;
+}
+inline hipError_t launch_theta(const PassArgs& a, int chunks, hipStream_t st) {
+  return launch_pass_t<8, DATA_BIN, MODE_T, 0>(a, chunks, st);
 }
 
 template <int DATA, int MODE>
@@ -526,7 +543,69 @@ int enqueue_exchange_after_sweep(nbmf_ctx* c, const PassArgs& a, bool with_produ
   return NBMF_OK;
 }
 
+// ---- n_components > 128: slices of SLICE_K components --------------------------------
+// Theta of the current factors into c->theta, in the tile order of image A (image 0: H-pass and loglik
+// sweeps) or image B (image 1: W-pass): one Theta-only sweep per slice, each adding onto the previous ones.
+int enqueue_theta(nbmf_ctx* c, int image) {
+  for (int sl = 0; sl < c->KS; ++sl) {
+    const size_t offW = (size_t)sl * SLICE_K * c->mA, offH = (size_t)sl * SLICE_K * c->nA;
+    PassArgs a{};
+    a.LT = image == 0 ? c->WT + offW : c->HT + offH;
+    a.LG = image == 0 ? c->WG + offW : c->HG + offH;   // not read by this mode
+    a.RfT = image == 0 ? c->HT + offH : c->WT + offW;
+    a.theta = c->theta;
+    a.accum = sl > 0;
+    a.done = c->flags;
+    a.Rb = (int)((image == 0 ? c->mA : c->nA) / 16);
+    a.Cb = (int)((image == 0 ? c->nA : c->mA) / 16);
+    a.chunk_start = image == 0 ? c->cstartH : c->cstartW;
+    a.C_alloc = image == 0 ? c->nA : c->mA;
+    a.eps = c->eps;
+    HIPCHK(launch_theta(a, image == 0 ? c->chunksH : c->chunksW, c->stream));
+  }
+  return NBMF_OK;
+}
+
+// the sweep of every slice over image A with Theta read back: back-products (with_products) or loglik only
+int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int clip) {
+  if (int rc = enqueue_theta(c, 0)) return rc;
+  const size_t per = (size_t)SLICE_K * c->nA;
+  for (int sl = 0; sl < (with_products ? c->KS : 1); ++sl) {
+    PassArgs a{};
+    a.data = c->dataA;
+    a.mask = c->maskA;
+    a.LT = c->WT;
+    a.LG = c->WG + (size_t)sl * SLICE_K * c->mA;
+    a.RfT = c->HT;
+    a.out1 = c->slabH + (size_t)sl * c->chunksH * per;
+    a.out2 = c->slabH + (size_t)(c->KS + sl) * c->chunksH * per;
+    a.lossbuf = sl == 0 ? c->lossbuf : nullptr;   // the likelihood is the same in every slice's sweep
+    a.done = c->flags;
+    a.Rb = (int)(c->mA / 16);
+    a.Cb = (int)(c->nA / 16);
+    a.chunk_start = c->cstartH;
+    a.C_alloc = c->nA;
+    a.eps = c->eps;
+    a.strict = strict;
+    a.clip = clip;
+    a.theta = c->theta;
+    if (with_products)
+      HIPCHK(launch_pass_slice<MODE_H>(c->data_kind, a, c->chunksH, c->stream));
+    else
+      HIPCHK(launch_pass_slice<MODE_L>(c->data_kind, a, c->chunksH, c->stream));
+  }
+  return NBMF_OK;
+}
+
 int enqueue_h_pass(nbmf_ctx* c) {
+  if (c->KS > 1) {
+    {
+      EvScope ev(c, 0);
+      if (int rc = enqueue_a_sweeps_sliced(c, true, 0, 0)) return rc;
+    }
+    c->ll_ptr = nullptr;
+    return NBMF_OK;
+  }
   PassArgs a{};
   a.data = c->dataA;
   a.mask = c->maskA;
@@ -553,6 +632,11 @@ int enqueue_h_pass(nbmf_ctx* c) {
 // Theta-only sweep (no back-products): the log-likelihood of the current factors at a third of the
 // H-pass's MFMA work; the per-wave partials land in lossbuf exactly as an H-pass leaves them.
 int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0) {
+  if (c->KS > 1) {
+    if (int rc = enqueue_a_sweeps_sliced(c, false, strict, clip)) return rc;
+    c->ll_ptr = nullptr;
+    return NBMF_OK;
+  }
   PassArgs a{};
   a.data = c->dataA;
   a.mask = c->maskA;
@@ -593,6 +677,24 @@ int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false, i
 }
 
 int enqueue_h_update(nbmf_ctx* c) {
+  if (c->KS > 1) {
+    // the update is elementwise in k: one launch per slice on that slice's rows of H and its slabs
+    const size_t per = (size_t)SLICE_K * c->nA;
+    const int blocks = (int)(per / 256);
+    for (int sl = 0; sl < c->KS; ++sl) {
+      const int ks = std::min(SLICE_K, c->k - sl * SLICE_K);
+      hipLaunchKernelGGL(h_update_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                         (const double*)(c->slabH + (size_t)sl * c->chunksH * per),
+                         (const double*)(c->slabH + (size_t)(c->KS + sl) * c->chunksH * per), c->chunksH, per, (long long)c->nA, 0LL,
+                         0LL, (long long)c->nA, c->Hn + sl * per, c->HT + sl * per, c->HG + sl * per,
+                         c->prior + 2 * (size_t)sl * blocks, ks, SLICE_K, (long long)c->n, (long long)c->nA, c->alpha - 1.0,
+                         c->beta - 1.0, c->eps, c->flags);
+      HIPCHK(hipGetLastError());
+    }
+    c->prior_src = c->prior;
+    c->n_prior_src = c->n_prior_blocks;
+    return NBMF_OK;
+  }
   // single GPU or column split: sum the H-pass slabs here, all columns in one launch
   const size_t per = (size_t)c->KP * c->nA;
   hipLaunchKernelGGL(h_update_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, (const double*)c->slabH,
@@ -625,9 +727,12 @@ PassArgs w_pass_args(nbmf_ctx* c) {
 }
 
 int enqueue_w_update(nbmf_ctx* c, const double* q, int chunks, double n_div, int projection) {
-  hipLaunchKernelGGL(w_update_kernel, dim3((unsigned)(c->mA / WU_COLS)), dim3(WU_COLS * WU_GROUPS),
-                     sizeof(double) * ((size_t)c->KP + 2) * WU_COLS, c->stream, q, chunks, c->Wn, c->WT, c->WG, c->k, c->KP,
-                     (long long)c->m, (long long)c->mA, n_div, c->rowcnt, projection, c->flags);
+  const size_t lds_bytes = sizeof(double) * ((size_t)c->KP + 2) * WU_COLS;
+  if (lds_bytes > 65536)
+    HIPCHK(hipFuncSetAttribute((const void*)w_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(w_update_kernel, dim3((unsigned)(c->mA / WU_COLS)), dim3(WU_COLS * WU_GROUPS), lds_bytes, c->stream, q,
+                     chunks, c->Wn, c->WT, c->WG, c->k, c->KP, std::min(c->KP, SLICE_K), (long long)c->m, (long long)c->mA, n_div,
+                     c->rowcnt, projection, c->flags);
   HIPCHK(hipGetLastError());
   return NBMF_OK;
 }
@@ -788,6 +893,20 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
 }
 
 int enqueue_w_step(nbmf_ctx* c, int projection) {
+  if (c->KS > 1) {
+    {
+      EvScope ev(c, 1);
+      if (int rc = enqueue_theta(c, 1)) return rc;
+      for (int sl = 0; sl < c->KS; ++sl) {
+        PassArgs w = w_pass_args(c);
+        w.LG = c->HG + (size_t)sl * SLICE_K * c->nA;
+        w.out1 = c->slabW + (size_t)sl * c->chunksW * SLICE_K * c->mA;
+        w.theta = c->theta;
+        HIPCHK(launch_pass_slice<MODE_W>(c->data_kind, w, c->chunksW, c->stream));
+      }
+    }
+    return enqueue_w_update(c, c->slabW, c->chunksW, (double)c->n, projection);
+  }
   PassArgs a = w_pass_args(c);
   {
     EvScope ev(c, 1);
@@ -966,7 +1085,9 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
   c->mA = round_up(m, PAD);
   c->nA = round_up(n, PAD);
   c->KB = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
-  c->KP = 16 * c->KB;
+  c->KS = (k + SLICE_K - 1) / SLICE_K;
+  c->KP = c->KS > 1 ? SLICE_K * c->KS : 16 * c->KB;
+  if (c->KS > 1) HIPCHK(hipMalloc(&c->theta, sizeof(double) * (size_t)c->mA * c->nA));
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
@@ -1006,7 +1127,7 @@ int nbmf_destroy(nbmf_ctx* c) {
   if (c->pflags) hipFree(c->pflags);
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
                   c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
-                  c->sbuf, c->Qbuf, c->cstartH, c->cstartW};
+                  c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (hipEvent_t e : c->ev) hipEventDestroy(e);
@@ -1215,7 +1336,7 @@ int nbmf_set_factors(nbmf_ctx* c, const double* W, const double* H) {
   {
     const long long tot = (long long)c->KP * c->mA;
     hipLaunchKernelGGL(set_factor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->stage, c->Wn,
-                       c->WT, c->WG, c->k, c->KP, (long long)c->m, (long long)c->mA);
+                       c->WT, c->WG, c->k, c->KP, std::min(c->KP, SLICE_K), (long long)c->m, (long long)c->mA);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1223,7 +1344,7 @@ int nbmf_set_factors(nbmf_ctx* c, const double* W, const double* H) {
   {
     const long long tot = (long long)c->KP * c->nA;
     hipLaunchKernelGGL(set_factor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->stage, c->Hn,
-                       c->HT, c->HG, c->k, c->KP, (long long)c->n, (long long)c->nA);
+                       c->HT, c->HG, c->k, c->KP, std::min(c->KP, SLICE_K), (long long)c->n, (long long)c->nA);
     HIPCHK(hipGetLastError());
   }
   hipLaunchKernelGGL(prior_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Hn, c->prior, c->k, c->KP,
@@ -1465,6 +1586,7 @@ static int comm_check_args(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   if (shard_axis != 0 && shard_axis != 1) return fail(NBMF_ERR_ARG, "shard_axis must be 0 (rows of Y) or 1 (columns of Y)");
   if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "call nbmf_upload before attaching a communicator (global counts are reduced there)");
   if (is_sharded(c)) return fail(NBMF_ERR_STATE, "a communicator is already attached (nbmf_comm_detach first)");
+  if (c->KS > 1) return fail(NBMF_ERR_ARG, "sharded runs support n_components <= %d (got %d)", SLICE_K, c->k);
   return NBMF_OK;
 }
 

@@ -65,7 +65,7 @@ def test_argument_errors_surface_without_a_gpu():
     h = ctypes.c_void_p()
     assert lib.nbmf_create(0, 5, 3, 0, ctypes.byref(h)) == _hip.NBMF_ERR_ARG
     assert b"m and n" in lib.nbmf_last_error()
-    assert lib.nbmf_create(5, 5, 129, 0, ctypes.byref(h)) == _hip.NBMF_ERR_ARG
+    assert lib.nbmf_create(5, 5, _hip.MAX_K + 1, 0, ctypes.byref(h)) == _hip.NBMF_ERR_ARG
     assert b"n_components" in lib.nbmf_last_error()
     assert lib.nbmf_run(None, 1, 0.0, None, None) == _hip.NBMF_ERR_ARG
     assert lib.nbmf_destroy(None) == 0

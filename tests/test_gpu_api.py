@@ -93,4 +93,4 @@ def test_extensions_n_init_projection_verbose(data, capsys):
     out = capsys.readouterr().out
     assert "Iter    0: Loss = " in out and "Iter   20: Loss = " in out           # _solver.py:165-166 text
     with pytest.raises(ValueError, match="n_components"):
-        NBMF(n_components=129, max_iter=2).fit(data)                              # K > 128 is refused loudly
+        NBMF(n_components=513, max_iter=2).fit(data)                              # beyond NBMF_MAX_K is refused loudly

@@ -258,7 +258,8 @@ def test_midsize_curves(hip, golden):
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 1, 1), (17, 5, 3), (130, 257, 17), (200, 129, 33), (64, 300, 100),
-                                   (129, 128, 128), (16, 16, 16)])
+                                   (129, 128, 128), (16, 16, 16),
+                                   (150, 200, 129), (257, 190, 256), (40, 333, 300)])   # > 128: slices sharing a stored Theta
 def test_ragged_shapes_vs_oracle(hip, m, n, k):
     """Edge shapes: not multiples of the 16x16 tile or the 128 padding; every K template."""
     r = np.random.default_rng(m * 1000 + n)
@@ -272,6 +273,53 @@ def test_ragged_shapes_vs_oracle(hip, m, n, k):
     np.testing.assert_allclose(l, lr, rtol=LOSS_RTOL, atol=0)
     np.testing.assert_allclose(W, Wr, rtol=0, atol=FACTOR_ATOL)
     np.testing.assert_allclose(H, Hr, rtol=0, atol=FACTOR_ATOL)
+
+
+def test_more_than_128_components(hip):
+    """n_components > 128 runs as slices of 128 (Theta kept in memory between the slices' sweeps): every storage
+    path, both orientations, the stop rule, transform / score, and the Duchi extension."""
+    from nbmf_mm_amd import NBMF, nbmf_mm_solver
+    r = np.random.default_rng(77)
+    m, n, k = 210, 301, 200
+    Y = (r.random((m, n)) < 0.35).astype(np.float64)
+    mask = r.random((m, n)) < 0.9
+    for kw in [dict(), dict(mask=mask), dict(orientation="dir-beta", mask=mask.astype(np.float64))]:
+        W, H, l, _, it = nbmf_mm_solver(Y, k, max_iter=15, tol=0, random_state=3, **kw)
+        Wr, Hr, lr, _, _ = orc.solve(Y, k, max_iter=15, tol=0, random_state=3, **kw)
+        np.testing.assert_allclose(l, lr, rtol=LOSS_RTOL, atol=0)
+        np.testing.assert_allclose(W, Wr, rtol=0, atol=FACTOR_ATOL)
+        np.testing.assert_allclose(H, Hr, rtol=0, atol=FACTOR_ATOL)
+    # real-valued data with weights (8-byte path)
+    Yr, Wt = r.random((m, n)), r.random((m, n))
+    W, H, l, _, _ = nbmf_mm_solver(Yr, 130, max_iter=10, tol=0, random_state=1, mask=Wt)
+    Wr, Hr, lr, _, _ = orc.solve(Yr, 130, max_iter=10, tol=0, random_state=1, mask=Wt)
+    np.testing.assert_allclose(l, lr, rtol=LOSS_RTOL, atol=0)
+    np.testing.assert_allclose(H, Hr, rtol=0, atol=FACTOR_ATOL)
+    # stop rule, bitwise repeatability, estimator surface
+    a = NBMF(n_components=k, random_state=5, max_iter=300, tol=1e-3).fit(Y, mask=mask)
+    _, _, lr, _, itr = orc.solve(Y, k, max_iter=300, tol=1e-3, random_state=5, mask=mask)
+    assert a.n_iter_ == itr and 2 < itr < 300
+    np.testing.assert_allclose(a.loss_curve_, lr, rtol=LOSS_RTOL, atol=0)
+    b = NBMF(n_components=k, random_state=5, max_iter=300, tol=1e-3).fit(Y, mask=mask)
+    np.testing.assert_array_equal(a.components_, b.components_)
+    # evaluation sweeps and the W-only step on pinned factors (transform()'s own random start is chaotic by design)
+    maskf = mask.astype(np.float64)
+    with hip.Context(m, n, k) as ctx:
+        ctx.set_hyper(1.2, 1.2)
+        ctx.upload(Y, mask=maskf)
+        ctx.set_factors(np.ascontiguousarray(a.W_.T), a.components_)
+        want = orc.score(Y, a.W_, a.components_, maskf)
+        assert abs(ctx.loglik(clip_theta=True) / ctx.n_obs() - want) <= 1e-12 * abs(want)
+        assert abs(ctx.loss() - orc.mm_loss(Y, a.W_.T, a.components_, maskf, 1.2, 1.2)) <= 1e-12
+        ctx.w_only_steps(2)
+        Wk, _ = ctx.get_factors()
+    Wr = _oracle_w_step(Y, a.components_, maskf, _oracle_w_step(Y, a.components_, maskf, a.W_))
+    np.testing.assert_allclose(Wk.T, Wr, rtol=0, atol=1e-11)
+    assert isinstance(a.score(Y, mask=mask), float) and a.transform(Y[:40]).shape == (40, k)
+    d = NBMF(n_components=k, random_state=5, max_iter=12, tol=0, projection="duchi").fit(Y, mask=mask)
+    _, _, ld, _, _ = orc.solve(Y, k, max_iter=12, tol=0, random_state=5, mask=mask, step=orc.mm_step_duchi)
+    np.testing.assert_allclose(d.loss_curve_, ld, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(d.W_.sum(axis=1), 1.0, atol=1e-12)
 
 
 def test_bitwise_run_to_run(hip):
