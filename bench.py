@@ -192,6 +192,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tim = ctx.timing()
+    replicas_identical = None
+    if world > 1:
+        # the replicated factor must be the same bits on every rank whatever the transport did (outside the timed region)
+        import hashlib
+        digest = hashlib.sha256(ctx.get_factors()[1].tobytes()).hexdigest()
+        table = [None] * world
+        dist.all_gather_object(table, (digest, [float(v) for v in losses]))
+        replicas_identical = all(t == table[0] for t in table)
     ctx.close()
 
     if rank == 0:
@@ -207,7 +215,7 @@ def main():
             "metric": "MM-iterations/sec", "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic (generated on device)" if args.device_data else "synthetic",
-            "final_nll_per_entry": float(losses[-1]),
+            "final_nll_per_entry": float(losses[-1]), "replicas_identical": replicas_identical,
             "loss_monotone": bool(all(losses[i] <= losses[i - 1] + 1e-12 for i in range(1, len(losses)))),
             "config": {"workload": f"NBMF-MM fit, dense binary V {M}x{N} (float64 API, density 0.25), K={K}, "
                                    f"{'mask 90% observed' if masked else 'no mask'}, projection={args.projection}, "
