@@ -46,7 +46,7 @@ extern "C" {
 #define NBMF_FLAG_BINARY_PATH 1 /* out_flags bit: data was {0,1} (and mask {0,1}) -> 1 byte/entry storage */
 
 #define NBMF_MAX_K 512        /* up to 128 components run in one fused sweep; more run as slices of 128 sharing a
-                                 stored Theta (single GPU only) */
+                                 stored Theta (8 bytes per entry of extra device memory) */
 
 typedef struct nbmf_ctx nbmf_ctx;
 

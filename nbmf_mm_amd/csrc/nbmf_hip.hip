@@ -603,8 +603,9 @@ int enqueue_h_pass(nbmf_ctx* c) {
       EvScope ev(c, 0);
       if (int rc = enqueue_a_sweeps_sliced(c, true, 0, 0)) return rc;
     }
-    c->ll_ptr = nullptr;
-    return NBMF_OK;
+    PassArgs a{};
+    a.Cb = (int)(c->nA / 16);
+    return enqueue_exchange_after_sweep(c, a, /*with_products=*/true, /*strict=*/0);
   }
   PassArgs a{};
   a.data = c->dataA;
@@ -634,8 +635,9 @@ int enqueue_h_pass(nbmf_ctx* c) {
 int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0) {
   if (c->KS > 1) {
     if (int rc = enqueue_a_sweeps_sliced(c, false, strict, clip)) return rc;
-    c->ll_ptr = nullptr;
-    return NBMF_OK;
+    PassArgs a{};
+    a.Cb = (int)(c->nA / 16);
+    return enqueue_exchange_after_sweep(c, a, /*with_products=*/false, strict);
   }
   PassArgs a{};
   a.data = c->dataA;
@@ -737,6 +739,43 @@ int enqueue_w_update(nbmf_ctx* c, const double* q, int chunks, double n_div, int
   return NBMF_OK;
 }
 
+// Rows of Y split: ordered sum of the H-pass slabs into [P1 | P2 | loglik] at `dst` (natural [KP][nA] twice);
+// with slices, one launch per slice on its rows.
+int enqueue_reduce_h_all(nbmf_ctx* c, double* dst, hipStream_t st) {
+  const int KSK = std::min(c->KP, SLICE_K);
+  const size_t per = (size_t)KSK * c->nA, tot = (size_t)c->KP * c->nA;
+  const int n_loss = c->chunksH * (int)(c->nA / 16 / WG_WAVES);
+  for (int sl = 0; sl < c->KS; ++sl) {
+    hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st,
+                       (const double*)(c->slabH + (size_t)sl * c->chunksH * per),
+                       (const double*)(c->slabH + (size_t)(c->KS + sl) * c->chunksH * per), c->chunksH, (long long)per,
+                       (long long)c->nA, 0LL, (long long)c->nA, KSK, dst + sl * per, dst + tot + sl * per,
+                       (const double*)c->lossbuf, n_loss, ll_pad_of(c), sl == 0 ? dst + 2 * tot : (double*)nullptr, c->flags);
+    HIPCHK(hipGetLastError());
+  }
+  return NBMF_OK;
+}
+
+// H-update of all columns from the summed products at `src` ([P1 | P2], natural), one launch per slice
+int enqueue_h_update_from(nbmf_ctx* c, const double* src, hipStream_t st) {
+  const int KSK = std::min(c->KP, SLICE_K);
+  const size_t per = (size_t)KSK * c->nA, tot = (size_t)c->KP * c->nA;
+  const int blocks = (int)(per / 256);
+  for (int sl = 0; sl < c->KS; ++sl) {
+    const int ks = std::min(KSK, c->k - sl * KSK);
+    hipLaunchKernelGGL(h_update_kernel, dim3(blocks), dim3(256), 0, st, src + sl * per, src + tot + sl * per, 1, (size_t)0,
+                       (long long)c->nA, 0LL, 0LL, (long long)c->nA, c->Hn + sl * per, c->HT + sl * per, c->HG + sl * per,
+                       c->prior + 2 * (size_t)sl * blocks, ks, KSK, (long long)c->n, (long long)c->nA, c->alpha - 1.0,
+                       c->beta - 1.0, c->eps, c->flags);
+    HIPCHK(hipGetLastError());
+  }
+  c->prior_src = c->prior;
+  c->n_prior_src = c->n_prior_blocks;
+  return NBMF_OK;
+}
+
+int enqueue_w_step(nbmf_ctx* c, int projection);
+
 // Rows of Y split, peer transport: the H-step exchange is this library's own reduce-scatter over xGMI with
 // the H-update fused in (each rank updates 1/R of the columns and broadcasts H', so the update is not
 // repeated R times and only K*N instead of 2*K*N doubles come back).  Order on the stream:
@@ -762,14 +801,14 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   a.eps = c->eps;
   {
     EvScope ev(c, 0);
-    HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
+    if (c->KS > 1) {
+      if (int rc = enqueue_a_sweeps_sliced(c, true, 0, 0)) return rc;
+    } else {
+      HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
+    }
   }
-  const int n_loss = c->chunksH * (a.Cb / WG_WAVES);
   double* X = c->arena;   // [P1 (KP x nA) | P2 (KP x nA) | loglik]
-  hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, (const double*)a.out1,
-                     (const double*)a.out2, c->chunksH, (long long)per, (long long)c->nA, 0LL, (long long)c->nA, c->KP, X,
-                     X + per, (const double*)c->lossbuf, n_loss, ll_pad_of(c), X + 2 * per, c->flags);
-  HIPCHK(hipGetLastError());
+  if (int rc = enqueue_reduce_h_all(c, X, c->stream)) return rc;
   const unsigned long long e = ++c->epoch;
   const unsigned long long hs = ++c->hseq;
   const int n_slots = PEER_H_WGS * c->pv.nranks;
@@ -785,16 +824,12 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, c->stream, c->pv, e, c->flags);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(peer_h_apply_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream,
-                     (const double*)(c->arena + c->offHX), c->Hn, c->HT, c->HG, c->KP, (long long)c->nA, c->flags);
+                     (const double*)(c->arena + c->offHX), c->Hn, c->HT, c->HG, c->KP, std::min(c->KP, SLICE_K),
+                     (long long)c->nA, c->flags);
   HIPCHK(hipGetLastError());
   c->prior_src = c->arena + offPR_now;
   c->n_prior_src = n_slots;
-  PassArgs w = w_pass_args(c);
-  {
-    EvScope ev(c, 1);
-    HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, w, c->chunksW, c->stream));
-  }
-  return enqueue_w_update(c, c->slabW, c->chunksW, (double)c->n, c->projection);
+  return enqueue_w_step(c, c->projection);   // the rows of W are local: no exchange in the W-step
 }
 
 // One whole iteration when the ROWS of Y are split over the ranks.  The exchange [P1 | P2 | loglik] is
@@ -804,6 +839,21 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
 // stream (it synchronises anyway); the arithmetic is the same.
 int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
   if (c->peer) return enqueue_iteration_rows_peer(c, it, tol);
+  if (c->KS > 1) {
+    // slices: one exchange of the whole [P1 | P2 | loglik], no panels
+    const size_t tot = (size_t)c->KP * c->nA;
+    {
+      EvScope ev(c, 0);
+      if (int rc = enqueue_a_sweeps_sliced(c, true, 0, 0)) return rc;
+    }
+    if (int rc = enqueue_reduce_h_all(c, c->Pbuf, c->stream)) return rc;
+    if (int rc = all_reduce_inplace(c, c->Pbuf, 2 * tot + 1)) return rc;
+    c->ll_ptr = c->Pbuf + 2 * tot;
+    if (it > 0)
+      if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;
+    if (int rc = enqueue_h_update_from(c, c->Pbuf, c->stream)) return rc;
+    return enqueue_w_step(c, c->projection);
+  }
   hipStream_t s0 = c->stream;
   const bool two_streams = c->npanel == 2 && c->comm && c->stream2;
   hipStream_t s1 = two_streams ? c->stream2 : s0;
@@ -904,6 +954,17 @@ int enqueue_w_step(nbmf_ctx* c, int projection) {
         w.theta = c->theta;
         HIPCHK(launch_pass_slice<MODE_W>(c->data_kind, w, c->chunksW, c->stream));
       }
+    }
+    if (is_sharded(c) && c->shard_axis == 1) {
+      // columns of Y split: sum every slice's slabs into its rows of Qbuf, one exchange of K_pad x m
+      const long long per = (long long)SLICE_K * c->mA;
+      for (int sl = 0; sl < c->KS; ++sl) {
+        hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double*)(c->slabW + (size_t)sl * c->chunksW * per), c->Qbuf + sl * per, c->chunksW, per, c->flags);
+        HIPCHK(hipGetLastError());
+      }
+      if (int rc = all_reduce_inplace(c, c->Qbuf, (size_t)c->KP * c->mA)) return rc;
+      return enqueue_w_update(c, c->Qbuf, 1, c->n_div_global, projection);
     }
     return enqueue_w_update(c, c->slabW, c->chunksW, (double)c->n, projection);
   }
@@ -1539,7 +1600,7 @@ static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   // with one rank, where there is nothing to hide); the break-even is an all-reduce of ~70 us, which cannot
   // be timed on a one-GPU box, so the default stays one panel.
   const char* ov = getenv("NBMF_OVERLAP");
-  c->npanel = (shard_axis == 0 && !c->peer && c->chunksW >= 2 && ov && atoi(ov) != 0) ? 2 : 1;
+  c->npanel = (shard_axis == 0 && !c->peer && c->KS == 1 && c->chunksW >= 2 && ov && atoi(ov) != 0) ? 2 : 1;
   c->wsplit = c->npanel == 2 ? c->chunksW / 2 : c->chunksW;
   c->pc0[0] = 0;
   c->pc0[1] = c->npanel == 2 ? (long long)c->bW_host[c->wsplit] * 16 : c->nA;
@@ -1586,7 +1647,6 @@ static int comm_check_args(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   if (shard_axis != 0 && shard_axis != 1) return fail(NBMF_ERR_ARG, "shard_axis must be 0 (rows of Y) or 1 (columns of Y)");
   if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "call nbmf_upload before attaching a communicator (global counts are reduced there)");
   if (is_sharded(c)) return fail(NBMF_ERR_STATE, "a communicator is already attached (nbmf_comm_detach first)");
-  if (c->KS > 1) return fail(NBMF_ERR_ARG, "sharded runs support n_components <= %d (got %d)", SLICE_K, c->k);
   return NBMF_OK;
 }
 

@@ -193,3 +193,42 @@ def test_missing_rank_times_out_instead_of_hanging():
     assert res[0][1] is not None and "timed out" in res[0][1]
     assert res[0][2] < 15.0
     assert res[0][3] == res[1][3] == 3
+
+
+def _worker_k200(rank, world, port, q):
+    dist = _setup(rank, world, port)
+    from nbmf_mm_amd import _dist
+    try:
+        M, N, K, Y, mask = _problem()
+        V, Vmask = Y[:300, :], mask[:300, :]
+        out = {}
+        r0, r1 = _dist.shard_bounds(V.shape[0], world, rank)
+        c0, c1 = _dist.shard_bounds(V.shape[1], world, rank)
+        for tr in ("peer", "host"):
+            out["rows_" + tr] = _dist.fit_sharded(V[r0:r1], V.shape, r0, 200, dist, shard="rows", max_iter=12, tol=0,
+                                                  mask_local=Vmask[r0:r1], random_state=4, device=0, transport=tr)
+            out["cols_" + tr] = _dist.fit_sharded(V[:, c0:c1], V.shape, c0, 200, dist, shard="cols", max_iter=12, tol=0,
+                                                  mask_local=Vmask[:, c0:c1], random_state=4, device=0, transport=tr)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_more_than_128_components():
+    """Slices (n_components > 128) under both splits and both transports, against the single-process run."""
+    from nbmf_mm_amd import nbmf_mm_solver
+    res = [o for _, o in _run(_worker_k200, 2)]
+    M, N, K, Y, mask = _problem()
+    V, Vmask = Y[:300, :], mask[:300, :]
+    W1, H1, l1, _, _ = nbmf_mm_solver(V, 200, max_iter=12, tol=0, mask=Vmask, random_state=4)
+    for tr in ("peer", "host"):
+        W = np.concatenate([r["rows_" + tr][0] for r in res], axis=0)
+        np.testing.assert_allclose(W, W1, rtol=0, atol=1e-12)
+        H = np.concatenate([r["cols_" + tr][1] for r in res], axis=1)
+        np.testing.assert_allclose(H, H1, rtol=0, atol=1e-12)
+        for r in res:
+            np.testing.assert_allclose(r["rows_" + tr][1], H1, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(r["cols_" + tr][0], W1, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(r["rows_" + tr][2], l1, rtol=1e-10, atol=0)
+            np.testing.assert_allclose(r["cols_" + tr][2], l1, rtol=1e-10, atol=0)
+        np.testing.assert_array_equal(res[0]["rows_" + tr][1], res[1]["rows_" + tr][1])
