@@ -151,6 +151,7 @@ def main():
         args.no_cpu_baseline = True
     else:
         X, Mk = make_shard(M, N, r0, r1, args.seed, masked=masked)
+        t_up = time.perf_counter()                     # the upload alone, not the synthetic generation before it
         binary_path = ctx.upload(X, mask=Mk)
         bytes_up = X.nbytes + (Mk.nbytes if masked else 0)
         del X, Mk
