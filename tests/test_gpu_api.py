@@ -94,3 +94,20 @@ def test_extensions_n_init_projection_verbose(data, capsys):
     assert "Iter    0: Loss = " in out and "Iter   20: Loss = " in out           # _solver.py:165-166 text
     with pytest.raises(ValueError, match="n_components"):
         NBMF(n_components=513, max_iter=2).fit(data)                              # beyond NBMF_MAX_K is refused loudly
+
+
+def test_large_input_range_check_happens_on_the_device():
+    """Above 2^24 entries fit() leaves "X must be binary" (_base.py:90-91) to the device pack, which sees every
+    entry anyway; the error and its wording are the reference's."""
+    from nbmf_mm_amd import NBMF
+    X = np.zeros((4100, 4100))
+    X[::7, ::5] = 1.0
+    assert X.size > (1 << 24)
+    m = NBMF(n_components=4, max_iter=2, tol=0, random_state=0).fit(X)
+    assert m.n_iter_ == 2
+    X[4099, 4097] = 1.5
+    with pytest.raises(ValueError, match="must be binary"):
+        NBMF(n_components=4, max_iter=2).fit(X)
+    X[4099, 4097] = np.nan
+    with pytest.raises(ValueError):                       # sklearn's check_array, as in the reference (:83)
+        NBMF(n_components=4, max_iter=2).fit(X)
