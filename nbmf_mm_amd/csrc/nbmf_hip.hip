@@ -814,18 +814,21 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   const int n_slots = PEER_H_WGS * c->pv.nranks;
   const long long offPR_now = c->offPR + (long long)(hs & 1) * 2 * PEER_H_WGS * PEER_MAX_RANKS;
   double* ll_slot = c->scal + 4;
+  // the loss and stop test of iteration it-1 ride in the same kernel (its first workgroup): they read the
+  // prior sums the PREVIOUS exchange left in the arena
+  const long long offPR_prev = c->prior_src ? (long long)(c->prior_src - c->arena) : 0;
+  const bool prev_in_arena = c->prior_src >= c->arena && c->prior_src < c->arena + c->arena_doubles;
+  const int fin_t = (it > 0 && prev_in_arena) ? it - 1 : -1;
   hipLaunchKernelGGL(peer_h_kernel, dim3(PEER_H_WGS), dim3(256), 0, c->stream, c->pv, e, (long long)per, (long long)(2 * per),
                      c->offHX, offPR_now, PEER_H_WGS * c->pv.rank, c->sl_c0, c->sl_wp, (const double*)c->Hn, c->k, c->KP,
-                     (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, ll_slot, c->flags);
+                     (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, ll_slot, c->flags, fin_t,
+                     offPR_prev, c->n_prior_src, c->n_obs_global, c->losses_d, tol, c->scal);
   HIPCHK(hipGetLastError());
   c->ll_ptr = ll_slot;
-  if (it > 0)
-    if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;   // reads the prior sums of the previous H-step
-  hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, c->stream, c->pv, e, c->flags);
-  HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(peer_h_apply_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream,
-                     (const double*)(c->arena + c->offHX), c->Hn, c->HT, c->HG, c->KP, std::min(c->KP, SLICE_K),
-                     (long long)c->nA, c->flags);
+  if (it > 0 && fin_t < 0)
+    if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;   // (first iteration after nbmf_set_factors: local prior sums)
+  hipLaunchKernelGGL(peer_h_apply_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, c->pv, e, c->offHX,
+                     c->Hn, c->HT, c->HG, c->KP, std::min(c->KP, SLICE_K), (long long)c->nA, c->flags);
   HIPCHK(hipGetLastError());
   c->prior_src = c->arena + offPR_now;
   c->n_prior_src = n_slots;
