@@ -43,7 +43,7 @@ def global_init(M, N, K, random_state, W_init=None, H_init=None):
     return np.ascontiguousarray(W), np.ascontiguousarray(H_init, dtype=np.float64)
 
 
-def attach_comm(ctx, dist, transport="rccl", shard_axis=0):
+def attach_comm(ctx, dist, transport="auto", shard_axis=0):
     """Join `ctx` to the job described by the initialised torch.distributed module `dist`.
 
     transport "peer": the library's own exchange kernels over xGMI (HIP-IPC mapped arenas; the H-update is
@@ -129,7 +129,7 @@ def attach_comm(ctx, dist, transport="rccl", shard_axis=0):
 
 def fit_row_sharded(Y_local, M_global, r0, n_components, dist, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
                     W_init=None, H_init=None, mask_local=None, random_state=None, eps=1e-8,
-                    projection="normalize", device=0, transport="rccl"):
+                    projection="normalize", device=0, transport="auto"):
     """beta-dir fit of the global (M_global x N) matrix whose rows [r0, r0+len(Y_local)) this rank
     holds.  Every rank must call this.  Returns (W_local (m_local,k), H (k,N), losses, n_iter)."""
     from ._solver import _projection_code
@@ -149,7 +149,7 @@ def fit_row_sharded(Y_local, M_global, r0, n_components, dist, max_iter=500, tol
 
 def fit_sharded(V_local, global_shape, offset, n_components, dist, orientation="beta-dir", shard="rows",
                 max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None, H_init=None, mask_local=None,
-                random_state=None, eps=1e-8, projection="normalize", device=0, transport="rccl"):
+                random_state=None, eps=1e-8, projection="normalize", device=0, transport="auto"):
     """Sharded fit in the user's orientation, V split over the ranks by ``shard`` = "rows"
     (``V_local = V[offset:offset+len, :]``) or "cols" (``V_local = V[:, offset:offset+len]``).
 
