@@ -609,3 +609,27 @@ def test_on_device_synthetic_data_matches_its_numpy_twin(hip):
             outs.append((losses,) + ctx.get_factors())
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+def test_seeded_sweep_of_configurations_vs_oracle(hip):
+    """Forty pseudo-random small problems (shape, K from 1 to 200, density, mask kind, orientation, priors,
+    real-valued or binary data, projection) against the oracle: the parity net under the hand-picked cases."""
+    from nbmf_mm_amd import nbmf_mm_solver
+    r = np.random.default_rng(20260101)
+    for case in range(40):
+        m, n = int(r.integers(1, 260)), int(r.integers(1, 300))
+        k = int(r.choice([1, 2, 5, 16, 17, 31, 48, 64, 65, 100, 128, 129, 200]))
+        binary = bool(r.integers(0, 4))                       # one in four real-valued
+        Y = (r.random((m, n)) < r.uniform(0.05, 0.6)).astype(np.float64) if binary else r.random((m, n))
+        mk = int(r.integers(0, 4))
+        mask = [None, r.random((m, n)) < 0.8, (r.random((m, n)) < 0.7).astype(np.float64), r.random((m, n))][mk]
+        orientation = "dir-beta" if r.integers(0, 2) else "beta-dir"
+        alpha, beta = float(r.uniform(1.0, 2.5)), float(r.uniform(1.0, 2.5))
+        duchi = bool(r.integers(0, 3) == 0)
+        kw = dict(max_iter=8, tol=0, alpha=alpha, beta=beta, mask=mask, random_state=case, orientation=orientation)
+        W, H, l, _, _ = nbmf_mm_solver(Y, k, projection="duchi" if duchi else "normalize", **kw)
+        Wr, Hr, lr, _, _ = orc.solve(Y, k, step=orc.mm_step_duchi if duchi else None, **kw)
+        tag = f"case {case}: {m}x{n} k={k} binary={binary} mask={mk} {orientation} duchi={duchi}"
+        np.testing.assert_allclose(l, lr, rtol=1e-9 if duchi else LOSS_RTOL, atol=0, err_msg=tag)
+        np.testing.assert_allclose(W, Wr, rtol=0, atol=FACTOR_ATOL, err_msg=tag)
+        np.testing.assert_allclose(H, Hr, rtol=0, atol=FACTOR_ATOL, err_msg=tag)
