@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "host"],
                     help="exchange transport for --gpus > 1: peer = the library's own kernels over xGMI (HIP IPC), rccl = RCCL "
-                         "all-reduce, host = gloo through pinned memory (tests only); auto = the first of these that attaches on every rank")
+                         "all-reduce, host = gloo through pinned memory (tests only); auto = peer and rccl are each timed over five "
+                         "iterations before the run and the faster one is kept")
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events around the pass kernels (overhead check)")
     ap.add_argument("--device-data", action="store_true",
                     help="generate the synthetic V / mask on the device (nbmf_generate) instead of uploading host arrays: "
@@ -158,9 +159,15 @@ def main():
         del X, Mk
     t_up = time.perf_counter() - t_up
     ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
-    transport = "none"
+    transport, trials = "none", None
     if world > 1:
-        transport = _dist.attach_comm(ctx, dist, args.transport)
+        if args.transport == "auto":
+            # time a few iterations over each transport that attaches and keep the faster one (setup, untimed)
+            def reset():
+                ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
+            transport, trials = _dist.attach_fastest(ctx, dist, reset)
+        else:
+            transport = _dist.attach_comm(ctx, dist, args.transport)
     elif args.force_comm:
         if args.transport == "peer":
             ctx.comm_init_peer(ctx.peer_export(0), 1, 0)
@@ -226,6 +233,7 @@ def main():
                                "property-tested); --projection normalize is the reference path, same kernels and the same "
                                "speed to within 0.2 % (DESIGN.md 5)",
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
+                       "transport_trials_s_per_5_iterations": trials,
                        "sharding": (f"rows/{world} ({transport}: " + ("reduce-scatter of 2*K*N+1 doubles fused with the H-update, K*N back"
                                                              if transport == "peer" else "all-reduce of 2*K*N+1 doubles")
                                     + " per iteration)") if world > 1 else "none"},

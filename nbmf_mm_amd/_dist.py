@@ -127,6 +127,46 @@ def attach_comm(ctx, dist, transport="auto", shard_axis=0):
     return host()
 
 
+def attach_fastest(ctx, dist, reset, shard_axis=0, candidates=("peer", "rccl"), iters=5):
+    """Attach whichever of ``candidates`` runs the iteration fastest on THIS machine: each one that attaches on
+    every rank is timed over ``iters`` iterations (max over ranks) and detached again; the winner is attached
+    for good (the host transport if none attaches).  ``reset()`` must restore the factors (``ctx.set_factors``)
+    -- it is called before every trial and once more at the end.  Returns ``(transport, {name: seconds})``."""
+    import time
+    import torch
+    timings = {}
+    for name in candidates:
+        try:
+            attach_comm(ctx, dist, name, shard_axis)
+        except _hip.NBMFHipError:
+            continue                                  # refused on some rank: every rank got the same answer
+        try:
+            reset()
+            ctx.run(2, 0.0)
+            ctx.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            ctx.run(int(iters), 0.0)
+            ctx.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            ok = 1
+        except _hip.NBMFHipError:
+            t, ok = torch.tensor([float("inf")], dtype=torch.float64), 0
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ctx.comm_detach()
+        if flag.item():
+            timings[name] = float(t.item())
+    if timings:
+        best = min(timings, key=timings.get)
+        attach_comm(ctx, dist, best, shard_axis)
+    else:
+        best = attach_comm(ctx, dist, "host", shard_axis)
+    reset()
+    return best, timings
+
+
 def fit_row_sharded(Y_local, M_global, r0, n_components, dist, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
                     W_init=None, H_init=None, mask_local=None, random_state=None, eps=1e-8,
                     projection="normalize", device=0, transport="auto"):

@@ -266,6 +266,7 @@ struct nbmf_ctx {
   unsigned long long* pflags = nullptr;
   size_t arena_doubles = 0;
   int arena_axis = -1;
+  char ipc_handles[NBMF_PEER_HANDLE_BYTES] = {0};   // of arena and flag block, valid while they are allocated
   bool peer = false;
   PeerView pv{};
   std::vector<void*> peer_mapped;   // hipIpcOpenMemHandle results to close
@@ -1709,26 +1710,32 @@ int nbmf_peer_export(nbmf_ctx* c, int shard_axis, void* handle) {
   if (is_sharded(c)) return fail(NBMF_ERR_STATE, "a communicator is already attached (nbmf_comm_detach first)");
   if (int rc = set_device(c)) return rc;
   static_assert(2 * sizeof(hipIpcMemHandle_t) <= NBMF_PEER_HANDLE_BYTES, "handle block too small");
-  // a fresh arena and flag block every time: epochs restart at zero on all ranks together
-  if (c->arena) HIPCHK(hipFree(c->arena));
-  if (c->pflags) HIPCHK(hipFree(c->pflags));
-  c->arena = nullptr;
-  c->pflags = nullptr;
-  peer_layout(c, shard_axis);
-  c->arena_doubles = (size_t)(c->offSC + 64);
-  c->arena_axis = shard_axis;
-  HIPCHK(hipExtMallocWithFlags((void**)&c->arena, c->arena_doubles * sizeof(double), hipDeviceMallocUncached));
-  HIPCHK(hipExtMallocWithFlags((void**)&c->pflags, PF_WORDS * sizeof(unsigned long long), hipDeviceMallocUncached));
+  // Epochs restart at zero on all ranks together: arena and flag block are cleared on every export (the
+  // ranks synchronise on the handle exchange before anyone signals).  The allocations and their IPC handles
+  // are kept for the life of the context when the axis does not change (re-exporting a freed-and-reallocated
+  // arena was refused by the runtime: hipIpcGetMemHandle "invalid argument").
+  if (!c->arena || c->arena_axis != shard_axis) {
+    if (c->arena) HIPCHK(hipFree(c->arena));
+    if (c->pflags) HIPCHK(hipFree(c->pflags));
+    c->arena = nullptr;
+    c->pflags = nullptr;
+    peer_layout(c, shard_axis);
+    c->arena_doubles = (size_t)(c->offSC + 64);
+    c->arena_axis = shard_axis;
+    HIPCHK(hipExtMallocWithFlags((void**)&c->arena, c->arena_doubles * sizeof(double), hipDeviceMallocUncached));
+    HIPCHK(hipExtMallocWithFlags((void**)&c->pflags, PF_WORDS * sizeof(unsigned long long), hipDeviceMallocUncached));
+    hipIpcMemHandle_t h[2];
+    HIPCHK(hipIpcGetMemHandle(&h[0], c->arena));
+    HIPCHK(hipIpcGetMemHandle(&h[1], c->pflags));
+    memset(c->ipc_handles, 0, sizeof c->ipc_handles);
+    memcpy(c->ipc_handles, h, sizeof h);
+  }
   HIPCHK(hipMemset(c->arena, 0, c->arena_doubles * sizeof(double)));
   HIPCHK(hipMemset(c->pflags, 0, PF_WORDS * sizeof(unsigned long long)));
   HIPCHK(hipDeviceSynchronize());
   c->epoch = 0;
   c->hseq = 0;
-  hipIpcMemHandle_t h[2];
-  HIPCHK(hipIpcGetMemHandle(&h[0], c->arena));
-  HIPCHK(hipIpcGetMemHandle(&h[1], c->pflags));
-  memset(handle, 0, NBMF_PEER_HANDLE_BYTES);
-  memcpy(handle, h, sizeof h);
+  memcpy(handle, c->ipc_handles, NBMF_PEER_HANDLE_BYTES);
   return NBMF_OK;
 }
 

@@ -195,3 +195,74 @@ def test_transport_negotiation_never_splits_the_job():
     assert res[1]["down_to_host"] == ("host", ["export", "rccl", "host"])
     assert res[0]["explicit"] == ("raised", ["export", "peer"])
     assert res[1]["explicit"] == ("raised", ["export", "peer", "detach"])
+
+
+def _worker_fastest(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import time
+    import torch.distributed as dist
+    from nbmf_mm_amd import _dist, _hip
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    _hip.comm_unique_id = lambda: bytes(128)
+
+    class Ctx(_StubCtx):
+        """Stub whose iterations are slow over the peer transport on rank 1 only."""
+        def __init__(self, fail=()):
+            super().__init__(fail)
+            self.attached = None
+
+        def comm_init_peer(self, *a):
+            super().comm_init_peer(*a)
+            self.attached = "peer"
+
+        def comm_init(self, *a):
+            super().comm_init(*a)
+            self.attached = "rccl"
+
+        def comm_detach(self):
+            super().comm_detach()
+            self.attached = None
+
+        def run(self, n, tol):
+            self.calls.append(f"run{n}")
+            if self.attached == "peer" and rank == 1:
+                time.sleep(0.05 * n)
+
+        def synchronize(self):
+            pass
+
+    try:
+        out = {}
+        c = Ctx()
+        resets = []
+        out["slow_peer"] = _dist.attach_fastest(c, dist, lambda: resets.append(1), iters=3) + (c.attached, len(resets))
+        c = Ctx(["rccl"] if rank == 0 else [])             # RCCL refuses on one rank: peer is the only candidate left
+        out["peer_only"] = _dist.attach_fastest(c, dist, lambda: None, iters=2)[0], c.attached
+        c = Ctx(["export", "rccl"])                        # nothing attaches: host transport
+        out["none"] = _dist.attach_fastest(c, dist, lambda: None, iters=2)[0], c.calls[-1]
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_attach_fastest_picks_by_the_slowest_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fastest, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [o for _, o in sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for r in res:
+        best, timings, attached, n_reset = r["slow_peer"]
+        assert best == "rccl" == attached and set(timings) == {"peer", "rccl"} and timings["peer"] > timings["rccl"]
+        assert n_reset == 3                                  # before each trial and after the final attach
+        assert r["peer_only"] == ("peer", "peer")
+        assert r["none"] == ("host", "host")
+    assert res[0]["slow_peer"][1] == res[1]["slow_peer"][1]  # the max over ranks is what every rank sees
