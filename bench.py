@@ -102,10 +102,11 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: --M rows PER GPU (e.g. --M 32768 --gpus 8 = BASELINE configs[3], 262144 x 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "host"],
+    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "rccl2", "host"],
                     help="exchange transport for --gpus > 1: peer = the library's own kernels over xGMI (HIP IPC), rccl = RCCL "
-                         "all-reduce, host = gloo through pinned memory (tests only); auto = peer and rccl are each timed over five "
-                         "iterations before the run and the faster one is kept")
+                         "all-reduce, host = gloo through pinned memory (tests only); rccl2 = RCCL in two "
+                         "overlapped panels; auto = peer, rccl and rccl2 are each timed over five iterations before the run and "
+                         "the fastest is kept")
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events around the pass kernels (overhead check)")
     ap.add_argument("--device-data", action="store_true",
                     help="generate the synthetic V / mask on the device (nbmf_generate) instead of uploading host arrays: "
@@ -235,7 +236,8 @@ def main():
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
                        "transport_trials_s_per_5_iterations": trials,
                        "sharding": (f"rows/{world} ({transport}: " + ("reduce-scatter of 2*K*N+1 doubles fused with the H-update, K*N back"
-                                                             if transport == "peer" else "all-reduce of 2*K*N+1 doubles")
+                                                             if transport == "peer" else "all-reduce of 2*K*N+1 doubles"
+                                                             + (" in two overlapped panels" if transport == "rccl2" else ""))
                                     + " per iteration)") if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -48,7 +48,8 @@ def attach_comm(ctx, dist, transport="auto", shard_axis=0):
 
     transport "peer": the library's own exchange kernels over xGMI (HIP-IPC mapped arenas; the H-update is
                       fused into a reduce-scatter).  One process per rank.
-    transport "rccl": RCCL all-reduce on the library's stream.
+    transport "rccl": RCCL all-reduce on the library's stream ("rccl2": in two column panels, the second
+                      overlapped with compute; rows split only).
     transport "host": all-reduce through pinned host memory and `dist` (tests, rehearsal on one GPU).
     transport "auto": peer, else RCCL, else host -- after each attempt the ranks agree (one all-reduce of a
                       flag over `dist`) whether it worked everywhere, so the job never splits.
@@ -113,6 +114,19 @@ def attach_comm(ctx, dist, transport="auto", shard_axis=0):
 
     if transport == "host":
         return host()
+    if transport == "rccl2":
+        # RCCL with the exchange cut into two column panels, the second overlapped with compute (NBMF_OVERLAP)
+        import os
+        old = os.environ.get("NBMF_OVERLAP")
+        os.environ["NBMF_OVERLAP"] = "1"
+        try:
+            attach_comm(ctx, dist, "rccl", shard_axis)
+        finally:
+            if old is None:
+                del os.environ["NBMF_OVERLAP"]
+            else:
+                os.environ["NBMF_OVERLAP"] = old
+        return "rccl2"
     if transport not in ("peer", "rccl", "auto"):
         raise ValueError(f"unknown transport {transport!r}")
     errors = []
@@ -127,7 +141,7 @@ def attach_comm(ctx, dist, transport="auto", shard_axis=0):
     return host()
 
 
-def attach_fastest(ctx, dist, reset, shard_axis=0, candidates=("peer", "rccl"), iters=5):
+def attach_fastest(ctx, dist, reset, shard_axis=0, candidates=("peer", "rccl", "rccl2"), iters=5):
     """Attach whichever of ``candidates`` runs the iteration fastest on THIS machine: each one that attaches on
     every rank is timed over ``iters`` iterations (max over ranks) and detached again; the winner is attached
     for good (the host transport if none attaches).  ``reset()`` must restore the factors (``ctx.set_factors``)

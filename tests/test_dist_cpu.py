@@ -261,8 +261,9 @@ def test_attach_fastest_picks_by_the_slowest_rank():
         assert p.exitcode == 0
     for r in res:
         best, timings, attached, n_reset = r["slow_peer"]
-        assert best == "rccl" == attached and set(timings) == {"peer", "rccl"} and timings["peer"] > timings["rccl"]
-        assert n_reset == 3                                  # before each trial and after the final attach
+        assert best in ("rccl", "rccl2") and attached == "rccl" and set(timings) == {"peer", "rccl", "rccl2"}
+        assert timings["peer"] > max(timings["rccl"], timings["rccl2"])
+        assert n_reset == 4                                  # before each trial and after the final attach
         assert r["peer_only"] == ("peer", "peer")
         assert r["none"] == ("host", "host")
     assert res[0]["slow_peer"][1] == res[1]["slow_peer"][1]  # the max over ranks is what every rank sees
