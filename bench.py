@@ -105,8 +105,8 @@ def main():
     ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "rccl2", "host"],
                     help="exchange transport for --gpus > 1: peer = the library's own kernels over xGMI (HIP IPC), rccl = RCCL "
                          "all-reduce, host = gloo through pinned memory (tests only); rccl2 = RCCL in two "
-                         "overlapped panels; auto = peer, rccl and rccl2 are each timed over five iterations before the run and "
-                         "the fastest is kept")
+                         "overlapped panels; auto = peer and rccl are each timed over five iterations before the run and the faster "
+                         "one is kept")
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events around the pass kernels (overhead check)")
     ap.add_argument("--device-data", action="store_true",
                     help="generate the synthetic V / mask on the device (nbmf_generate) instead of uploading host arrays: "

@@ -141,11 +141,13 @@ def attach_comm(ctx, dist, transport="auto", shard_axis=0):
     return host()
 
 
-def attach_fastest(ctx, dist, reset, shard_axis=0, candidates=("peer", "rccl", "rccl2"), iters=5):
+def attach_fastest(ctx, dist, reset, shard_axis=0, candidates=("peer", "rccl"), iters=5):
     """Attach whichever of ``candidates`` runs the iteration fastest on THIS machine: each one that attaches on
     every rank is timed over ``iters`` iterations (max over ranks) and detached again; the winner is attached
     for good (the host transport if none attaches).  ``reset()`` must restore the factors (``ctx.set_factors``)
-    -- it is called before every trial and once more at the end.  Returns ``(transport, {name: seconds})``."""
+    -- it is called before every trial and once more at the end.  Returns ``(transport, {name: seconds})``.
+    ("rccl2" may be added to ``candidates``; it is not a default because it keeps two collectives of one
+    communicator in flight on two streams, which has only been exercised with a single rank.)"""
     import time
     import torch
     timings = {}

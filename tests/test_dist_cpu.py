@@ -237,7 +237,8 @@ def _worker_fastest(rank, world, port, q):
         out = {}
         c = Ctx()
         resets = []
-        out["slow_peer"] = _dist.attach_fastest(c, dist, lambda: resets.append(1), iters=3) + (c.attached, len(resets))
+        out["slow_peer"] = _dist.attach_fastest(c, dist, lambda: resets.append(1), candidates=("peer", "rccl", "rccl2"),
+                                                iters=3) + (c.attached, len(resets))
         c = Ctx(["rccl"] if rank == 0 else [])             # RCCL refuses on one rank: peer is the only candidate left
         out["peer_only"] = _dist.attach_fastest(c, dist, lambda: None, iters=2)[0], c.attached
         c = Ctx(["export", "rccl"])                        # nothing attaches: host transport
