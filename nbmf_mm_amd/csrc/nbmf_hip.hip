@@ -52,6 +52,9 @@
 #ifndef NBMF_SADDR
 #define NBMF_SADDR 1   // stage/code loads addressed as scalar base + lane offset (see STAGE_DMA)
 #endif
+#ifndef NBMF_XCD_MAP
+#define NBMF_XCD_MAP 1   // give each XCD whole chunks of a sweep (see pass_kernel)
+#endif
 #ifndef NBMF_LDS_DMA
 #define NBMF_LDS_DMA 1   // stage the factor panels with global_load_lds (LDS-DMA); 0 = through registers
 #endif
