@@ -161,9 +161,11 @@ int nbmf_synchronize(nbmf_ctx* ctx);
 
 /* Self-test hook used by the GPU tests: applies one of the pass kernel's scalar device routines to n
  * caller-supplied values (op 0: Newton reciprocal used on the binary path; op 1: the natural logarithm
- * of the general path) so the host can compare with IEEE 1/x and log(x). */
+ * of the general path; op 2: the general path's quotient, evaluated as (1 - 0.75 x) / x) so the host can
+ * compare with IEEE 1/x, log(x) and the IEEE quotient. */
 #define NBMF_SELFTEST_RCP 0
 #define NBMF_SELFTEST_LOG 1
+#define NBMF_SELFTEST_DIV 2
 int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y);
 
 #ifdef __cplusplus

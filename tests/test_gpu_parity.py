@@ -46,6 +46,20 @@ def test_reciprocal_accuracy(hip):
     assert (ulp == 0).mean() > 0.9
 
 
+def test_quotient_accuracy(hip):
+    # quotient of the general (real-valued / weighted) path: the correctly rounded IEEE quotient for nearly every
+    # argument, never more than 1 ulp away; exact zeros stay exact
+    r = np.random.default_rng(2)
+    d = np.concatenate([np.exp(r.uniform(np.log(1e-8), 0.0, 1 << 20)) + 1e-8, r.uniform(0.0, 1.0, 1 << 18) + 1e-8,
+                        [1e-8, 1.0 + 1e-8, 0.5, 4.0 / 3.0]])
+    got = hip.selftest_unary(2, d)
+    want = (1.0 - 0.75 * d) / d
+    ulp = np.abs(got - want) / np.maximum(np.spacing(np.abs(want)), 5e-324)
+    assert ulp.max() <= 1.0, ulp.max()
+    assert (ulp == 0).mean() > 0.999
+    assert hip.selftest_unary(2, np.array([4.0 / 3.0]))[0] == (1.0 - 0.75 * (4.0 / 3.0)) / (4.0 / 3.0)
+
+
 def test_log_accuracy(hip):
     # logarithm of the general path: <= 1 ulp of the correctly rounded value on (0, 2], same special
     # values as NumPy elsewhere
