@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -285,7 +286,7 @@ struct nbmf_ctx {
   unsigned long long* pflags = nullptr;
   size_t arena_doubles = 0;
   int arena_axis = -1;
-  char ipc_handles[NBMF_PEER_HANDLE_BYTES] = {0};   // of arena and flag block, valid while they are allocated
+  struct ArenaSlotRef { void* p = nullptr; } arena_slot;   // pool entry behind arena / pflags (ArenaSlot*)
   bool peer = false;
   PeerView pv{};
   std::vector<void*> peer_mapped;   // hipIpcOpenMemHandle results to close
@@ -346,6 +347,72 @@ constexpr int kNcclSum = 0;       // ncclSum
     if (r_ != 0)                                                                                          \
       return fail(NBMF_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
   } while (0)
+
+// ---- peer-transport arenas: a process-wide pool ---------------------------------------------------
+// Memory that has been exported through HIP IPC is never given back to the allocator while the process lives:
+// a context returns its arena (payload block + flag block + their IPC handles) to this pool and the next
+// context of a fitting size takes it over.  Freeing an exported arena and exporting a fresh allocation that
+// lands on the same address handed the peers a mapping of the OLD memory (seen as a wrong factor in the second
+// of two sharded fits in one process); a handle that stays valid for good cannot go stale.
+struct ArenaSlot {
+  int device;
+  size_t doubles;
+  double* arena;
+  unsigned long long* flags;
+  char handles[NBMF_PEER_HANDLE_BYTES];
+  bool in_use;
+};
+std::vector<ArenaSlot*> g_arenas;
+std::mutex g_arena_mu;
+
+int arena_acquire(int device, size_t doubles, ArenaSlot** out) {
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  ArenaSlot* best = nullptr;
+  for (ArenaSlot* a : g_arenas)
+    if (!a->in_use && a->device == device && a->doubles >= doubles && a->doubles <= 4 * doubles + (1u << 20) &&
+        (!best || a->doubles < best->doubles))
+      best = a;
+  if (!best) {
+    ArenaSlot* a = new ArenaSlot();
+    a->device = device;
+    a->doubles = doubles;
+    a->arena = nullptr;
+    a->flags = nullptr;
+    a->in_use = false;
+    hipError_t e = hipExtMallocWithFlags((void**)&a->arena, doubles * sizeof(double), hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipExtMallocWithFlags((void**)&a->flags, PF_WORDS * sizeof(unsigned long long), hipDeviceMallocUncached);
+    hipIpcMemHandle_t h[2];
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h[0], a->arena);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h[1], a->flags);
+    if (e != hipSuccess) {
+      if (a->arena) hipFree(a->arena);   // never exported: safe to free
+      if (a->flags) hipFree(a->flags);
+      delete a;
+      return fail(NBMF_ERR_HIP, "peer arena: %s (allocation or hipIpcGetMemHandle)", hipGetErrorString(e));
+    }
+    static_assert(2 * sizeof(hipIpcMemHandle_t) <= NBMF_PEER_HANDLE_BYTES, "handle block too small");
+    memset(a->handles, 0, sizeof a->handles);
+    memcpy(a->handles, h, sizeof h);
+    g_arenas.push_back(a);
+    best = a;
+  }
+  best->in_use = true;
+  *out = best;
+  return NBMF_OK;
+}
+
+void arena_release(ArenaSlot* a) {
+  if (!a) return;
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  a->in_use = false;
+  if (const char* e = getenv("NBMF_ARENA_POOL"))
+    if (atoi(e) == 0) {   // diagnostic: the old behaviour (free on release), to reproduce the stale-mapping failure
+      hipFree(a->arena);
+      hipFree(a->flags);
+      g_arenas.erase(std::find(g_arenas.begin(), g_arenas.end(), a));
+      delete a;
+    }
+}
 
 // ---- pass launch ----------------------------------------------------------------------------
 template <int KB, int DATA, int MODE, int TH = 0>
@@ -440,7 +507,12 @@ void pick_chunks(int strips_groups, int Rb, int NB, int slots, int* chunks, int*
   const int max_chunks = std::max(1, Rb / NB);
   want = std::min(std::max(want, 1), max_chunks);
   int ch = (Rb + want - 1) / want;
-  ch = std::max(ch, std::min(Rb, 64));
+  // (small problems -- fewer than 512 workgroups even at 64-block chunks -- are bound by the length of the
+  //  sweep a single workgroup walks, not by per-workgroup overhead: 8-block chunks there.  BASELINE configs[0],
+  //  100 x 500 with K = 6: 37.4 -> 26.2 us per iteration (26 700 -> 38 100 iterations/s); the 36-fit
+  //  perplexity grid on the lastfm-sized matrix 0.63 -> 0.33 s.)
+  const int min_blocks = (long long)strips_groups * ((Rb + 63) / 64) >= 512 ? 64 : 8;
+  ch = std::max(ch, std::min(Rb, min_blocks));
   ch = (int)round_up(ch, NB);
   *CH = ch;
   *chunks = (Rb + ch - 1) / ch;
@@ -1207,8 +1279,7 @@ int nbmf_destroy(nbmf_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   comm_release(c);
   if (c->host_buf) hipHostFree(c->host_buf);
-  if (c->arena) hipFree(c->arena);
-  if (c->pflags) hipFree(c->pflags);
+  arena_release((ArenaSlot*)c->arena_slot.p);   // back to the pool, never to the allocator (see ArenaSlot)
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
                   c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
                   c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta};
@@ -1728,33 +1799,29 @@ int nbmf_peer_export(nbmf_ctx* c, int shard_axis, void* handle) {
   if (shard_axis != 0 && shard_axis != 1) return fail(NBMF_ERR_ARG, "shard_axis must be 0 or 1");
   if (is_sharded(c)) return fail(NBMF_ERR_STATE, "a communicator is already attached (nbmf_comm_detach first)");
   if (int rc = set_device(c)) return rc;
-  static_assert(2 * sizeof(hipIpcMemHandle_t) <= NBMF_PEER_HANDLE_BYTES, "handle block too small");
   // Epochs restart at zero on all ranks together: arena and flag block are cleared on every export (the
-  // ranks synchronise on the handle exchange before anyone signals).  The allocations and their IPC handles
-  // are kept for the life of the context when the axis does not change (re-exporting a freed-and-reallocated
-  // arena was refused by the runtime: hipIpcGetMemHandle "invalid argument").
+  // ranks synchronise on the handle exchange before anyone signals).  The memory comes from the process-wide
+  // pool and keeps its IPC handles for the life of the process.
   if (!c->arena || c->arena_axis != shard_axis) {
-    if (c->arena) HIPCHK(hipFree(c->arena));
-    if (c->pflags) HIPCHK(hipFree(c->pflags));
+    arena_release((ArenaSlot*)c->arena_slot.p);
+    c->arena_slot.p = nullptr;
     c->arena = nullptr;
     c->pflags = nullptr;
     peer_layout(c, shard_axis);
-    c->arena_doubles = (size_t)(c->offSC + 64);
+    ArenaSlot* slot = nullptr;
+    if (int rc = arena_acquire(c->device, (size_t)(c->offSC + 64), &slot)) return rc;
+    c->arena_slot.p = slot;
+    c->arena = slot->arena;
+    c->pflags = slot->flags;
+    c->arena_doubles = slot->doubles;
     c->arena_axis = shard_axis;
-    HIPCHK(hipExtMallocWithFlags((void**)&c->arena, c->arena_doubles * sizeof(double), hipDeviceMallocUncached));
-    HIPCHK(hipExtMallocWithFlags((void**)&c->pflags, PF_WORDS * sizeof(unsigned long long), hipDeviceMallocUncached));
-    hipIpcMemHandle_t h[2];
-    HIPCHK(hipIpcGetMemHandle(&h[0], c->arena));
-    HIPCHK(hipIpcGetMemHandle(&h[1], c->pflags));
-    memset(c->ipc_handles, 0, sizeof c->ipc_handles);
-    memcpy(c->ipc_handles, h, sizeof h);
   }
   HIPCHK(hipMemset(c->arena, 0, c->arena_doubles * sizeof(double)));
   HIPCHK(hipMemset(c->pflags, 0, PF_WORDS * sizeof(unsigned long long)));
   HIPCHK(hipDeviceSynchronize());
   c->epoch = 0;
   c->hseq = 0;
-  memcpy(handle, c->ipc_handles, NBMF_PEER_HANDLE_BYTES);
+  memcpy(handle, ((ArenaSlot*)c->arena_slot.p)->handles, NBMF_PEER_HANDLE_BYTES);
   return NBMF_OK;
 }
 

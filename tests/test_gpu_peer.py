@@ -232,3 +232,47 @@ def test_sharded_more_than_128_components():
             np.testing.assert_allclose(r["rows_" + tr][2], l1, rtol=1e-10, atol=0)
             np.testing.assert_allclose(r["cols_" + tr][2], l1, rtol=1e-10, atol=0)
         np.testing.assert_array_equal(res[0]["rows_" + tr][1], res[1]["rows_" + tr][1])
+
+
+_SEQ = [("rows", 24), ("cols", 9), ("rows", 24), ("cols", 200), ("rows", 130), ("cols", 9), ("cols", 24), ("rows", 9)]
+
+
+def _worker_sequence(rank, world, port, q):
+    dist = _setup(rank, world, port)
+    from nbmf_mm_amd import _dist
+    try:
+        M, N, K, Y, mask = _problem()
+        V, Vmask = Y[:300, :], mask[:300, :]
+        out = []
+        for shard, k in _SEQ:
+            lo, hi = _dist.shard_bounds(V.shape[0 if shard == "rows" else 1], world, rank)
+            sl = (slice(lo, hi), slice(None)) if shard == "rows" else (slice(None), slice(lo, hi))
+            out.append(_dist.fit_sharded(V[sl], V.shape, lo, k, dist, shard=shard, max_iter=6, tol=0, mask_local=Vmask[sl],
+                                         random_state=4, device=0, transport="peer"))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_many_sharded_fits_in_one_process():
+    """Contexts come and go, arenas of different sizes and axes are exported again and again: every fit must see
+    the peers' CURRENT arenas (the IPC-exported memory is pooled per process and never freed, so a handle cannot
+    come to mean stale memory)."""
+    from nbmf_mm_amd import nbmf_mm_solver
+    res = [o for _, o in _run(_worker_sequence, 2)]
+    M, N, K, Y, mask = _problem()
+    V, Vmask = Y[:300, :], mask[:300, :]
+    single = {}
+    for i, (shard, k) in enumerate(_SEQ):
+        if k not in single:
+            single[k] = nbmf_mm_solver(V, k, max_iter=6, tol=0, mask=Vmask, random_state=4)
+        W1, H1, l1 = single[k][:3]
+        if shard == "rows":
+            W = np.concatenate([r[i][0] for r in res], axis=0)
+            H = res[0][i][1]
+        else:
+            W = res[0][i][0]
+            H = np.concatenate([r[i][1] for r in res], axis=1)
+        np.testing.assert_allclose(W, W1, rtol=0, atol=1e-12, err_msg=f"fit {i}: {shard} k={k}")
+        np.testing.assert_allclose(H, H1, rtol=0, atol=1e-12, err_msg=f"fit {i}: {shard} k={k}")
+        np.testing.assert_allclose(res[1][i][2], l1, rtol=1e-10, atol=0)
