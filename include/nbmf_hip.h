@@ -73,6 +73,14 @@ int nbmf_set_hyper(nbmf_ctx* ctx, double alpha, double beta, double eps, int pro
 int nbmf_upload(nbmf_ctx* ctx, const double* x, int64_t ldx, int transposed,
                 const void* mask, int mask_kind, int64_t ldmask, int* out_flags);
 
+/* Sparse upload of BINARY data: the user's matrix given as a CSR pattern (canonical: sorted or not, but no
+ * duplicate entries; every stored entry means 1), optionally with a second CSR pattern of the OBSERVED entries
+ * (mask_indptr NULL = everything observed).  Replaces `Y = Y.toarray()` of _solver.py:28-29 / _base.py:86-87
+ * plus the pack: the dense matrix is never formed, on the host or on the device (1 byte per entry and image, as
+ * for dense binary data).  indptr has rows+1 entries of the user's matrix (m, or n when transposed != 0). */
+int nbmf_upload_csr(nbmf_ctx* ctx, const int64_t* indptr, const int32_t* indices, int64_t nnz, int transposed,
+                    const int64_t* mask_indptr, const int32_t* mask_indices, int64_t mask_nnz, int* out_flags);
+
 /* Measurement helper with no reference counterpart: fill the context with synthetic BINARY data generated on
  * the device instead of nbmf_upload -- entry (i, j) of the internal m x n matrix is 1 with probability
  * `density` and observed with probability `observed`, from a counter-based hash of (seed, i*n + j)

@@ -29,7 +29,7 @@ PEER_HANDLE_BYTES = 128
 #: every symbol include/nbmf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "nbmf_abi_version", "nbmf_last_error", "nbmf_device_count", "nbmf_create", "nbmf_destroy",
-    "nbmf_set_hyper", "nbmf_upload", "nbmf_generate", "nbmf_get_n_obs", "nbmf_set_factors", "nbmf_get_factors",
+    "nbmf_set_hyper", "nbmf_upload", "nbmf_upload_csr", "nbmf_generate", "nbmf_get_n_obs", "nbmf_set_factors", "nbmf_get_factors",
     "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_loglik", "nbmf_loglik_strict", "nbmf_comm_unique_id", "nbmf_comm_init",
     "nbmf_comm_init_host", "nbmf_peer_export", "nbmf_comm_init_peer", "nbmf_comm_detach",
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
@@ -89,6 +89,7 @@ def load():
     lib.nbmf_comm_unique_id.argtypes = [c_void_p]
     lib.nbmf_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int]
     lib.nbmf_comm_init_host.argtypes = [c_void_p, HOST_ALLREDUCE_FN, c_void_p, c_int, c_int, c_int]
+    lib.nbmf_upload_csr.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, POINTER(c_int)]
     lib.nbmf_peer_export.argtypes = [c_void_p, c_int, c_void_p]
     lib.nbmf_comm_init_peer.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int]
     lib.nbmf_comm_detach.argtypes = [c_void_p]
@@ -177,6 +178,26 @@ class Context:
                                      mptr, kind, ldm, byref(flags)))
         self.binary_path = bool(flags.value & FLAG_BINARY_PATH)
         return self.binary_path
+
+    def upload_csr(self, x_pattern, mask_pattern=None, transposed=False):
+        """Binary data from CSR patterns: ``x_pattern`` / ``mask_pattern`` are ``(indptr, indices)`` pairs of the
+        user's matrix (rows = its rows) whose stored entries mean 1 / observed; no dense copy is made anywhere."""
+        def prep(p):
+            ip = np.ascontiguousarray(p[0], dtype=np.int64)
+            ix = np.ascontiguousarray(p[1], dtype=np.int32)
+            rows = self.n if transposed else self.m
+            if ip.shape != (rows + 1,) or ix.shape != (int(ip[-1]),):
+                raise ValueError(f"CSR pattern does not describe {rows} rows")
+            return ip, ix
+        ip, ix = prep(x_pattern)
+        mp, mx = prep(mask_pattern) if mask_pattern is not None else (None, None)
+        flags = c_int(0)
+        _check(self._lib.nbmf_upload_csr(
+            self._h, ip.ctypes.data_as(c_void_p), ix.ctypes.data_as(c_void_p), int(ix.size), int(bool(transposed)),
+            None if mp is None else mp.ctypes.data_as(c_void_p), None if mx is None else mx.ctypes.data_as(c_void_p),
+            0 if mx is None else int(mx.size), byref(flags)))
+        self.binary_path = True
+        return True
 
     def generate(self, seed, density=0.25, observed=1.0):
         """Fill the context with synthetic binary data generated on the device (see synthetic_reference)."""

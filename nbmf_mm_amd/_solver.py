@@ -28,6 +28,19 @@ def _draw_init(m, k, n, W_init, H_init):
     return W_init, H_init
 
 
+def _binary_pattern(A):
+    """``(indptr, indices)`` of a scipy sparse matrix whose stored values are all 1 (after summing duplicates
+    and dropping explicit zeros), else None."""
+    A = A.tocsr(copy=True)
+    A.sum_duplicates()
+    A.eliminate_zeros()
+    if A.nnz and not np.all(A.data == 1):
+        return None
+    if A.shape[1] >= 2 ** 31:
+        return None
+    return A.indptr.astype(np.int64), A.indices.astype(np.int32)
+
+
 def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None,
                    H_init=None, mask=None, random_state=None, verbose=0, orientation="beta-dir",
                    eps=1e-8, projection="normalize", device=0, _ctx_hook=None):
@@ -41,9 +54,21 @@ def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
         raise ValueError("max_iter must be >= 1")      # the reference dies with UnboundLocalError here (:215)
     if random_state is not None:
         np.random.seed(random_state)                   # GLOBAL legacy RNG, as :102-103
-    if mask is not None and hasattr(mask, "toarray"):
+    # Sparse input: the reference densifies (:28-29,106-107).  Binary patterns stay sparse all the way to the
+    # device (nbmf_upload_csr); anything else is densified here as the reference does.
+    csr = csr_mask = None
+    if hasattr(Y, "toarray"):
+        csr = _binary_pattern(Y)
+        if csr is not None and mask is not None:
+            csr_mask = _binary_pattern(mask) if hasattr(mask, "toarray") else None
+            if csr_mask is None:
+                csr = None
+        if csr is None:
+            Y = Y.toarray()
+    if csr is None and mask is not None and hasattr(mask, "toarray"):
         mask = mask.toarray()                          # :106-107
-    Y = np.asarray(Y)
+    if csr is None:
+        Y = np.asarray(Y)
     m, n = Y.shape
     k = int(n_components)
     transposed = orientation == "dir-beta"
@@ -62,7 +87,10 @@ def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
     with _hip.Context(m, n, k, device=device) as ctx:
         ctx.set_hyper(alpha, beta, eps, proj)
         # the user's array goes up untransposed; the pack kernel applies the orientation
-        ctx.upload(Y, mask=mask, transposed=transposed)
+        if csr is not None:
+            ctx.upload_csr(csr, csr_mask, transposed=transposed)
+        else:
+            ctx.upload(Y, mask=mask, transposed=transposed)
         if _ctx_hook is not None:
             _ctx_hook(ctx)
         ctx.set_factors(W, H)

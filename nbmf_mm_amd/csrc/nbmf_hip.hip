@@ -1477,6 +1477,78 @@ int nbmf_generate(nbmf_ctx* c, uint64_t seed, double density, double observed) {
   return NBMF_OK;
 }
 
+int nbmf_upload_csr(nbmf_ctx* c, const int64_t* indptr, const int32_t* indices, int64_t nnz, int transposed,
+                    const int64_t* mask_indptr, const int32_t* mask_indices, int64_t mask_nnz, int* out_flags) {
+  if (!c || !indptr || (nnz > 0 && !indices)) return fail(NBMF_ERR_ARG, "null context or CSR arrays");
+  if (nnz < 0 || mask_nnz < 0) return fail(NBMF_ERR_ARG, "negative entry count");
+  const bool masked = mask_indptr != nullptr;
+  if (masked && mask_nnz > 0 && !mask_indices) return fail(NBMF_ERR_ARG, "mask_indptr without mask_indices");
+  if (is_sharded(c)) return fail(NBMF_ERR_STATE, "upload before attaching a communicator");
+  if (int rc = set_device(c)) return rc;
+  const int64_t U = transposed ? c->n : c->m, V = transposed ? c->m : c->n;   // the user's matrix is U x V
+  if (indptr[0] != 0 || indptr[U] != nnz) return fail(NBMF_ERR_ARG, "indptr does not span the %lld stored entries", (long long)nnz);
+  if (masked && (mask_indptr[0] != 0 || mask_indptr[U] != mask_nnz)) return fail(NBMF_ERR_ARG, "mask indptr does not span its entries");
+  for (void** p : {&c->dataA, &c->dataB, &c->maskA, &c->maskB}) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  c->data_kind = -1;
+  const long long RbA = c->mA / 16, RbB = c->nA / 16;
+  const size_t tiles = (size_t)RbA * RbB;
+  HIPCHK(hipMalloc(&c->dataA, tiles * 256));
+  HIPCHK(hipMalloc(&c->dataB, tiles * 256));
+  HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
+  const long long dwords = (long long)tiles * 64;
+  hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)c->dataA,
+                     (uint32_t*)c->dataB, RbA, RbB, (long long)c->m, (long long)c->n,
+                     masked ? (unsigned)CB_VALID : (unsigned)(CB_VALID | CB_ZOBS));
+  HIPCHK(hipGetLastError());
+  // the two patterns, staged through the device in pieces of at most 64 M entries
+  struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+      if (p) hipFree(p);
+    }
+  } d_ptr, d_idx;
+  HIPCHK(hipMalloc(&d_ptr.p, sizeof(int64_t) * (size_t)(U + 1)));
+  const int64_t piece = 64ll << 20;
+  HIPCHK(hipMalloc(&d_idx.p, sizeof(int32_t) * (size_t)std::max<int64_t>(1, std::min<int64_t>(piece, std::max(nnz, mask_nnz)))));
+  for (int what = masked ? 0 : 1; what <= 1; ++what) {
+    const int64_t* ip = what == 0 ? mask_indptr : indptr;
+    const int32_t* ix = what == 0 ? mask_indices : indices;
+    const int64_t cnt = what == 0 ? mask_nnz : nnz;
+    HIPCHK(hipMemcpyAsync(d_ptr.p, ip, sizeof(int64_t) * (size_t)(U + 1), hipMemcpyHostToDevice, c->stream));
+    for (int64_t e0 = 0; e0 < cnt; e0 += piece) {
+      const int64_t ne = std::min(piece, cnt - e0);
+      HIPCHK(hipMemcpyAsync(d_idx.p, ix + e0, sizeof(int32_t) * (size_t)ne, hipMemcpyHostToDevice, c->stream));
+      // the kernel indexes entries from e0: shift the view of indices, keep indptr absolute
+      hipLaunchKernelGGL(csr_scatter_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream,
+                         (const long long*)d_ptr.p, (const int*)d_idx.p - e0, (long long)U, (long long)V, (long long)e0,
+                         (long long)(e0 + ne), transposed, what, (unsigned char*)c->dataA, (unsigned char*)c->dataB, RbA, RbB, c->stats);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(c->stream));   // the staging buffer is reused by the next piece
+    }
+  }
+  if (masked) {
+    hipLaunchKernelGGL(count_observed_kernel, dim3(1024), dim3(256), 0, c->stream, (const uint32_t*)c->dataA, dwords, c->stats);
+    HIPCHK(hipGetLastError());
+  }
+  unsigned long long st[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(st, c->stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (st[1] != 0) return fail(NBMF_ERR_ARG, "%llu column indices outside [0, %lld)", st[1], (long long)V);
+  c->data_kind = DATA_BIN;
+  if (int rc2 = setup_workspaces(c)) return rc2;
+  c->n_obs = masked ? (double)st[0] : (double)c->m * (double)c->n;
+  c->n_obs_global = c->n_obs;
+  hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
+                     c->data_kind, (long long)(c->nA / 16), (long long)c->m, c->rowcnt);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (out_flags) *out_flags = NBMF_FLAG_BINARY_PATH;
+  return NBMF_OK;
+}
+
 int nbmf_get_n_obs(nbmf_ctx* c, double* n_obs) {
   if (!c || !n_obs) return fail(NBMF_ERR_ARG, "null argument");
   if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "nbmf_upload has not been called");

@@ -111,3 +111,51 @@ def test_large_input_range_check_happens_on_the_device():
     X[4099, 4097] = np.nan
     with pytest.raises(ValueError):                       # sklearn's check_array, as in the reference (:83)
         NBMF(n_components=4, max_iter=2).fit(X)
+
+
+def test_sparse_input_stays_sparse_and_matches_dense():
+    """scipy CSR input with binary values (and an optional sparse pattern mask) is packed on the device from the
+    CSR arrays; the fit is bit-identical to the dense one.  Non-binary values or a dense mask take the
+    reference's route (densify) and still agree."""
+    import scipy.sparse as sp
+    from nbmf_mm_amd import NBMF, nbmf_mm_solver, _hip
+    r = np.random.default_rng(5)
+    m, n, k = 333, 517, 12
+    Xd = (r.random((m, n)) < 0.07).astype(np.float64)
+    Xd[17, :] = 0.0                                           # an empty row
+    Md = r.random((m, n)) < 0.8
+    X = sp.csr_matrix(Xd)
+    X.indices = X.indices.astype(np.int64)                    # any index width
+    M = sp.coo_matrix(Md.astype(np.float64))                  # any sparse format
+    calls = []
+    orig = _hip.Context.upload_csr
+    _hip.Context.upload_csr = lambda self, *a, **kw: (calls.append(1), orig(self, *a, **kw))[1]
+    try:
+        for kw_s, kw_d in [(dict(), dict()), (dict(mask=M), dict(mask=Md)),
+                           (dict(mask=M, orientation="dir-beta"), dict(mask=Md, orientation="dir-beta"))]:
+            a = nbmf_mm_solver(X, k, max_iter=15, tol=0, random_state=1, **kw_s)
+            b = nbmf_mm_solver(Xd, k, max_iter=15, tol=0, random_state=1, **kw_d)
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+            np.testing.assert_array_equal(a[2], b[2])
+        assert len(calls) == 3
+        e = NBMF(n_components=k, max_iter=15, tol=0, random_state=1).fit(X, mask=M)
+        d = NBMF(n_components=k, max_iter=15, tol=0, random_state=1).fit(Xd, mask=Md)
+        np.testing.assert_array_equal(e.components_, d.components_)
+        assert len(calls) == 4
+        # weights in the sparse matrix, or a dense mask: densified as in the reference, same answer as dense input
+        Xw = X.copy()
+        Xw.data[::3] = 0.5
+        a = nbmf_mm_solver(Xw, k, max_iter=5, tol=0, random_state=1)
+        b = nbmf_mm_solver(Xw.toarray(), k, max_iter=5, tol=0, random_state=1)
+        np.testing.assert_array_equal(a[2], b[2])
+        a = nbmf_mm_solver(X, k, max_iter=5, tol=0, random_state=1, mask=Md)
+        b = nbmf_mm_solver(Xd, k, max_iter=5, tol=0, random_state=1, mask=Md)
+        np.testing.assert_array_equal(a[2], b[2])
+        assert len(calls) == 4
+        Xbad = X.copy()
+        Xbad.data[0] = 1.5
+        with pytest.raises(ValueError, match="must be binary"):
+            NBMF(n_components=k, max_iter=2).fit(Xbad)
+    finally:
+        _hip.Context.upload_csr = orig
