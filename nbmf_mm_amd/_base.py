@@ -128,9 +128,7 @@ class NBMFMM(BaseEstimator, TransformerMixin):
         """Find W for new rows X with ``components_`` frozen: 50 simplex-factor updates from a
         draw of the global NumPy RNG (_base.py:162-199)."""
         check_is_fitted(self, ["components_"])
-        X = self._validated(X)
-        if mask is not None and hasattr(mask, "toarray"):
-            mask = mask.toarray()
+        X = self._validated(X, keep_sparse=True)
         return w_only_transform(X, self.components_, mask=mask, n_iter=50, device=self.device)
 
     def inverse_transform(self, W):
@@ -143,9 +141,7 @@ class NBMFMM(BaseEstimator, TransformerMixin):
         """Mean log-likelihood per observed entry of the reconstruction (_base.py:212-247).
         As in the reference the inner ``transform`` is called WITHOUT the mask (:235)."""
         check_is_fitted(self, ["components_"])
-        X = self._validated(X)
-        if mask is not None and hasattr(mask, "toarray"):
-            mask = mask.toarray()
+        X = self._validated(X, keep_sparse=True)
         H = np.asarray(self.components_, dtype=np.float64)
         return device_score(X, H, mask=mask, n_iter=50, device=self.device)
 

@@ -188,14 +188,15 @@ def fit_row_sharded(Y_local, M_global, r0, n_components, dist, max_iter=500, tol
                     projection="normalize", device=0, transport="auto"):
     """beta-dir fit of the global (M_global x N) matrix whose rows [r0, r0+len(Y_local)) this rank
     holds.  Every rank must call this.  Returns (W_local (m_local,k), H (k,N), losses, n_iter)."""
-    from ._solver import _projection_code
-    Y_local = np.asarray(Y_local, dtype=np.float64)
+    from ._solver import _projection_code, upload_any
+    if not hasattr(Y_local, "toarray"):
+        Y_local = np.asarray(Y_local, dtype=np.float64)
     m_loc, N = Y_local.shape
     K = int(n_components)
     W, H = global_init(M_global, N, K, random_state, W_init, H_init)
     with _hip.Context(m_loc, N, K, device=device) as ctx:
         ctx.set_hyper(alpha, beta, eps, _projection_code(projection))
-        ctx.upload(Y_local, mask=mask_local)
+        upload_any(ctx, Y_local, mask_local)
         ctx.set_factors(np.ascontiguousarray(W[:, r0:r0 + m_loc]), H)
         attach_comm(ctx, dist, transport)
         losses, n_iter = ctx.run(int(max_iter), float(tol))
@@ -216,8 +217,9 @@ def fit_sharded(V_local, global_shape, offset, n_components, dist, orientation="
     returns ``(W, H, losses, n_iter)`` with W (rows_here, k) and H (k, cols_here).
     Custom inits are GLOBAL arrays; under dir-beta they are swapped only if BOTH are given (:122-123).
     """
-    from ._solver import _projection_code
-    V_local = np.asarray(V_local, dtype=np.float64)
+    from ._solver import _projection_code, upload_any
+    if not hasattr(V_local, "toarray"):
+        V_local = np.asarray(V_local, dtype=np.float64)
     M, N = global_shape
     K = int(n_components)
     if orientation not in ("beta-dir", "dir-beta"):
@@ -240,7 +242,7 @@ def fit_sharded(V_local, global_shape, offset, n_components, dist, orientation="
         ctx_shape, W0, H0, axis = (m_int, length), Wi, Hi[:, sl], 1
     with _hip.Context(ctx_shape[0], ctx_shape[1], K, device=device) as ctx:
         ctx.set_hyper(alpha, beta, eps, _projection_code(projection))
-        ctx.upload(V_local, mask=mask_local, transposed=transposed)    # the pack kernel applies the transpose
+        upload_any(ctx, V_local, mask_local, transposed=transposed)    # the pack applies the transpose
         ctx.set_factors(np.ascontiguousarray(W0), np.ascontiguousarray(H0))
         attach_comm(ctx, dist, transport, shard_axis=axis)
         losses, n_iter = ctx.run(int(max_iter), float(tol))

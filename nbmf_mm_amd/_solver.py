@@ -41,6 +41,24 @@ def _binary_pattern(A):
     return A.indptr.astype(np.int64), A.indices.astype(np.int32)
 
 
+def upload_any(ctx, X, mask=None, transposed=False):
+    """Upload dense or scipy-sparse data: binary sparse patterns (with no mask or a sparse pattern mask) go up as
+    CSR (``nbmf_upload_csr``); everything else is densified first, as the reference does (:28-29,106-107)."""
+    if hasattr(X, "toarray"):
+        csr = _binary_pattern(X)
+        csr_mask = None
+        if csr is not None and mask is not None:
+            csr_mask = _binary_pattern(mask) if hasattr(mask, "toarray") else None
+            if csr_mask is None:
+                csr = None
+        if csr is not None:
+            return ctx.upload_csr(csr, csr_mask, transposed=transposed)
+        X = X.toarray()
+    if mask is not None and hasattr(mask, "toarray"):
+        mask = mask.toarray()
+    return ctx.upload(np.asarray(X, dtype=np.float64), mask=mask, transposed=transposed)
+
+
 def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None,
                    H_init=None, mask=None, random_state=None, verbose=0, orientation="beta-dir",
                    eps=1e-8, projection="normalize", device=0, _ctx_hook=None):
@@ -54,20 +72,8 @@ def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
         raise ValueError("max_iter must be >= 1")      # the reference dies with UnboundLocalError here (:215)
     if random_state is not None:
         np.random.seed(random_state)                   # GLOBAL legacy RNG, as :102-103
-    # Sparse input: the reference densifies (:28-29,106-107).  Binary patterns stay sparse all the way to the
-    # device (nbmf_upload_csr); anything else is densified here as the reference does.
-    csr = csr_mask = None
-    if hasattr(Y, "toarray"):
-        csr = _binary_pattern(Y)
-        if csr is not None and mask is not None:
-            csr_mask = _binary_pattern(mask) if hasattr(mask, "toarray") else None
-            if csr_mask is None:
-                csr = None
-        if csr is None:
-            Y = Y.toarray()
-    if csr is None and mask is not None and hasattr(mask, "toarray"):
-        mask = mask.toarray()                          # :106-107
-    if csr is None:
+    # (sparse input: the reference densifies, :28-29,106-107; here upload_any keeps binary patterns sparse)
+    if not hasattr(Y, "toarray"):
         Y = np.asarray(Y)
     m, n = Y.shape
     k = int(n_components)
@@ -87,10 +93,7 @@ def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
     with _hip.Context(m, n, k, device=device) as ctx:
         ctx.set_hyper(alpha, beta, eps, proj)
         # the user's array goes up untransposed; the pack kernel applies the orientation
-        if csr is not None:
-            ctx.upload_csr(csr, csr_mask, transposed=transposed)
-        else:
-            ctx.upload(Y, mask=mask, transposed=transposed)
+        upload_any(ctx, Y, mask, transposed=transposed)
         if _ctx_hook is not None:
             _ctx_hook(ctx)
         ctx.set_factors(W, H)
@@ -138,14 +141,15 @@ def _touch_up(W_final, H_final, orientation):
 def w_only_transform(X, H, mask=None, W0=None, n_iter=50, device=0):
     """The loop of ``NBMFMM.transform`` (src/nbmf_mm/_base.py:170-199) on the GPU: ``n_iter``
     simplex-factor updates with ``H`` frozen, then clip to [1e-8, 1] and row-renormalise."""
-    X = np.asarray(X, dtype=np.float64)
+    if not hasattr(X, "toarray"):
+        X = np.asarray(X, dtype=np.float64)
     m, n = X.shape
     k = H.shape[0]
     if W0 is None:
         W0 = np.random.uniform(0.1, 0.9, (m, k))      # global RNG, :175
     with _hip.Context(m, n, k, device=device) as ctx:
         ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_NORMALIZE)   # eps is hard-coded 1e-8 at :190
-        ctx.upload(X, mask=mask, transposed=False)
+        upload_any(ctx, X, mask)
         ctx.set_factors(np.ascontiguousarray(W0.T), H)
         ctx.w_only_steps(int(n_iter))
         Wk, _ = ctx.get_factors()
@@ -159,20 +163,21 @@ def device_score(X, H, mask=None, n_iter=50, device=0):
     """``NBMFMM.score`` on the GPU (src/nbmf_mm/_base.py:212-247): the inner transform runs WITHOUT
     the mask (:235), then the mean log-likelihood per observed entry of W @ H under ``mask``.
     The reference clips W @ H to [0, 1] first (:210); so does the device sweep (clip_theta)."""
-    X = np.asarray(X, dtype=np.float64)
+    if not hasattr(X, "toarray"):
+        X = np.asarray(X, dtype=np.float64)
     m, n = X.shape
     k = H.shape[0]
     W0 = np.random.uniform(0.1, 0.9, (m, k))          # global RNG, :175
     with _hip.Context(m, n, k, device=device) as ctx:
         ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_NORMALIZE)
-        ctx.upload(X, mask=None, transposed=False)
+        upload_any(ctx, X, None)
         ctx.set_factors(np.ascontiguousarray(W0.T), H)
         ctx.w_only_steps(int(n_iter))
         Wk, _ = ctx.get_factors()
         W = np.clip(Wk.T, 1e-8, 1.0)                  # :196
         W = W / W.sum(axis=1, keepdims=True)          # :198
         if mask is not None:
-            ctx.upload(X, mask=mask, transposed=False)
+            upload_any(ctx, X, mask)
         ctx.set_factors(np.ascontiguousarray(W.T), H)
         ll = ctx.loglik(clip_theta=True)
         n_obs = ctx.n_obs()

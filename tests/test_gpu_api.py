@@ -153,6 +153,17 @@ def test_sparse_input_stays_sparse_and_matches_dense():
         b = nbmf_mm_solver(Xd, k, max_iter=5, tol=0, random_state=1, mask=Md)
         np.testing.assert_array_equal(a[2], b[2])
         assert len(calls) == 4
+        # transform / score / perplexity and the sharded helpers take the same route
+        np.random.seed(3)
+        ts = e.transform(X[:64], mask=sp.csr_matrix(Md[:64].astype(np.float64)))
+        np.random.seed(3)
+        td = d.transform(Xd[:64], mask=Md[:64])
+        np.testing.assert_array_equal(ts, td)
+        np.random.seed(4)
+        ss = e.score(X, mask=M)
+        np.random.seed(4)
+        assert ss == d.score(Xd, mask=Md)
+        assert len(calls) == 4 + 1 + 2                        # transform once; score: unmasked transform + masked sweep
         Xbad = X.copy()
         Xbad.data[0] = 1.5
         with pytest.raises(ValueError, match="must be binary"):
