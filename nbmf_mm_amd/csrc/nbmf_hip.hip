@@ -1511,7 +1511,8 @@ int nbmf_upload_csr(nbmf_ctx* c, const int64_t* indptr, const int32_t* indices, 
     }
   } d_ptr, d_idx;
   HIPCHK(hipMalloc(&d_ptr.p, sizeof(int64_t) * (size_t)(U + 1)));
-  const int64_t piece = 64ll << 20;
+  int64_t piece = 64ll << 20;
+  if (const char* e = getenv("NBMF_CSR_PIECE")) piece = std::max<int64_t>(1, atoll(e));   // (tests: force several pieces)
   HIPCHK(hipMalloc(&d_idx.p, sizeof(int32_t) * (size_t)std::max<int64_t>(1, std::min<int64_t>(piece, std::max(nnz, mask_nnz)))));
   for (int what = masked ? 0 : 1; what <= 1; ++what) {
     const int64_t* ip = what == 0 ? mask_indptr : indptr;

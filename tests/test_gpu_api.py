@@ -1,5 +1,7 @@
 """The reference's behavioural contract (its tests/ directory) re-stated against the drop-in:
 shapes, constraints, monotone loss, aliases, reproducibility, sklearn protocol, extensions."""
+import os
+
 import numpy as np
 import pytest
 
@@ -139,6 +141,13 @@ def test_sparse_input_stays_sparse_and_matches_dense():
             np.testing.assert_array_equal(a[1], b[1])
             np.testing.assert_array_equal(a[2], b[2])
         assert len(calls) == 3
+        os.environ["NBMF_CSR_PIECE"] = "1000"                 # the staged upload in many pieces
+        try:
+            a = nbmf_mm_solver(X, k, max_iter=15, tol=0, random_state=1, mask=M, orientation="dir-beta")
+        finally:
+            del os.environ["NBMF_CSR_PIECE"]
+        np.testing.assert_array_equal(a[2], b[2])
+        calls.pop()
         e = NBMF(n_components=k, max_iter=15, tol=0, random_state=1).fit(X, mask=M)
         d = NBMF(n_components=k, max_iter=15, tol=0, random_state=1).fit(Xd, mask=Md)
         np.testing.assert_array_equal(e.components_, d.components_)
