@@ -327,6 +327,15 @@ def test_more_than_128_components(hip):
         assert abs(ctx.loss() - orc.mm_loss(Y, a.W_.T, a.components_, maskf, 1.2, 1.2)) <= 1e-12
         ctx.w_only_steps(2)
         Wk, _ = ctx.get_factors()
+    # strictly masked held-out log-likelihood (examples/reproduce_magron2022.py:40-47) through the slices
+    from nbmf_mm_amd.experiments import heldout_perplexity
+    held = ~mask
+    with hip.Context(m, n, k) as ev:
+        ev.set_hyper(1.0, 1.0)
+        ev.upload(Y, mask=held)
+        got = heldout_perplexity(ev, np.ascontiguousarray(a.W_.T), a.components_)
+    want = orc.heldout_perplexity(Y, a.W_ @ a.components_, held.astype(np.float64))
+    assert abs(got - want) <= 1e-12 * want
     Wr = _oracle_w_step(Y, a.components_, maskf, _oracle_w_step(Y, a.components_, maskf, a.W_))
     np.testing.assert_allclose(Wk.T, Wr, rtol=0, atol=1e-11)
     assert isinstance(a.score(Y, mask=mask), float) and a.transform(Y[:40]).shape == (40, k)
