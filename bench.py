@@ -143,7 +143,10 @@ def main():
     r0, r1 = _dist.shard_bounds(M, world, rank)
 
     W_full, H0 = init_factors(M, N, K, args.seed)
-    ctx = _hip.Context(r1 - r0, N, K, device=0 if args.share_gpu else local_rank)   # one rank = one GPU
+    # one rank = one GPU; if the launcher has narrowed every rank's view to its own card, that card is device 0
+    n_visible = _hip.device_count()
+    dev_index = 0 if (args.share_gpu or local_rank >= n_visible) else local_rank
+    ctx = _hip.Context(r1 - r0, N, K, device=dev_index)
     ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_DUCHI if args.projection == "duchi" else _hip.PROJ_NORMALIZE)
     t_up = time.perf_counter()
     if args.device_data:
@@ -177,7 +180,7 @@ def main():
             ctx.comm_init(_hip.comm_unique_id(), 1, 0)
             transport = "rccl(1 rank)"
 
-    dev = 0 if args.share_gpu else local_rank
+    dev = dev_index
     if torch.cuda.is_available():
         torch.cuda.set_device(dev)
 
