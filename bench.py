@@ -7,12 +7,17 @@ count).  One "step" = one MM iteration = H-step + W-step + loss (src/nbmf_mm/_so
 the reference).  With --gpus N the SAME V is row-sharded over N ranks (strong scaling); every
 iteration all-reduces the K x N H-step products over RCCL.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
-torch.distributed.run (one rank per GPU).  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N>1 it runs one process per GPU: either a
+launcher has already started the ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the
+environment, e.g. by PyTorch's distributed launcher, which is how the driver starts N>1), or -- invoked
+plainly -- this script starts N children of itself before anything touches a GPU and waits for them.  The
+ranks meet through nbmf_mm_amd._rendezvous (standard library); PyTorch is not imported.  Rank 0 prints ONE
+JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,8 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet fp64 matrix = 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
-PEAK_MEASURED_TFLOPS = 71.5        # bare back-to-back v_mfma_f64_16x16x4_f64 on all 1024 SIMDs at the clock the chip holds (tools/microbench.hip)
-                               # (measured back-to-back v_mfma_f64_16x16x4_f64: 71.5 TFLOP/s)
+PEAK_MEASURED_TFLOPS = 71.5    # bare back-to-back v_mfma_f64_16x16x4_f64 on all 1024 SIMDs at the clock the chip holds (tools/microbench.hip)
 
 
 def make_shard(M, N, r0, r1, seed, density=0.25, observed=0.9, masked=True):
@@ -52,9 +56,10 @@ def init_factors(M, N, K, seed):
     return np.ascontiguousarray(W), H0
 
 
-def cpu_baseline(N, K, seed, masked, budget_rows=2048, iters=3):
+def cpu_baseline(N, K, seed, masked, projection, budget_rows=2048, iters=3):
     """The CPU oracle (NumPy port of the reference iteration) timed on this host on a bounded
-    sample: the first `budget_rows` rows of the same V; cost is linear in M at fixed N, K."""
+    sample: the first `budget_rows` rows of the same V; cost is linear in M at fixed N, K.
+    Returns (seconds per iteration, BLAS threads, loss after the 1 + iters iterations it ran)."""
     from oracle import nbmf_oracle as orc
     try:
         import threadpoolctl
@@ -62,30 +67,88 @@ def cpu_baseline(N, K, seed, masked, budget_rows=2048, iters=3):
         threads = max([d.get("num_threads", 1) for d in info] or [1])
     except Exception:
         threads = len(os.sched_getaffinity(0))
+    step = orc.mm_step_duchi if projection == "duchi" else orc.mm_step
     X, Mk = make_shard(budget_rows, N, 0, budget_rows, seed, masked=masked)
     mask = Mk.astype(np.float64) if masked else None
     W, H = init_factors(budget_rows, N, K, seed)
-    W, H = orc.mm_step(X, W, H, mask, 1.2, 1.2)            # warm-up
+    W, H = step(X, W, H, mask, 1.2, 1.2)                   # warm-up
     t0 = time.perf_counter()
     for _ in range(iters):
-        W, H = orc.mm_step(X, W, H, mask, 1.2, 1.2)
+        W, H = step(X, W, H, mask, 1.2, 1.2)
         loss = orc.mm_loss(X, W, H, mask, 1.2, 1.2)
     dt = (time.perf_counter() - t0) / iters
     return dt, threads, float(loss)
 
 
+def hip_sample_loss(N, K, seed, masked, projection, device, budget_rows=2048, iters=3):
+    """The HIP path on the very sample cpu_baseline() ran (same rows, init and 1 + iters iterations): its final
+    loss, for the bench line's `parity` field."""
+    from nbmf_mm_amd import _hip
+    X, Mk = make_shard(budget_rows, N, 0, budget_rows, seed, masked=masked)
+    W, H = init_factors(budget_rows, N, K, seed)
+    with _hip.Context(budget_rows, N, K, device=device) as ctx:
+        ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_DUCHI if projection == "duchi" else _hip.PROJ_NORMALIZE)
+        ctx.upload(X, mask=Mk)
+        ctx.set_factors(W, H)
+        losses, _ = ctx.run(1 + iters, 0.0)
+    return float(losses[-1])
+
+
+def host_ram_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemTotal:"):
+                return round(int(line.split()[1]) / 1048576.0, 1)
+    except OSError:
+        pass
+    return None
+
+
 def profiled_traffic(M, N, K, masked, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/r1_c3_k64_masked.json <- tools/prof_summary.py): (2*FETCH_SIZE + WRITE_SIZE) KiB,
-    the x2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  Only for the
-    default workload on one GPU; otherwise None."""
-    path = os.path.join(ROOT, "profiles", "r1_c3_k64_masked.json")
-    if (M, N, K, masked, world) != (65536, 8192, 64, True, 1) or not os.path.exists(path):
+    command (profiles/r*_c3_k64_masked.json <- tools/prof_summary.py; the newest round's file wins):
+    (2*FETCH_SIZE + WRITE_SIZE) KiB, the x2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md
+    (HBM section).  Only for the default workload on one GPU; otherwise None."""
+    if (M, N, K, masked, world) != (65536, 8192, 64, True, 1):
         return None, None
-    rec = json.load(open(path))
-    if "FETCH_SIZE" not in rec or "WRITE_SIZE" not in rec:
-        return None, None
-    return (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0, "profiles/r1_c3_k64_masked.json"
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_k64_masked.json")), reverse=True):
+        rec = json.load(open(path))
+        if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+            return (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def launch_ranks(n):
+    """`bench.py --gpus N` invoked plainly: start N children of this script, one per GPU, BEFORE this process
+    has touched a GPU (it never does), wait for them, and pass on the worst exit code.  Rank 0's child prints
+    the JSON line on the stdout it inherits."""
+    from nbmf_mm_amd import _rendezvous
+    port = _rendezvous.free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:                         # one rank failed: the others would wait for it forever
+                    rc = rc or code
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -121,33 +184,36 @@ def main():
 
     if args.overlap:
         os.environ["NBMF_OVERLAP"] = "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))       # plain invocation: this process only starts the ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
 
-    import torch            # plumbing only: rendezvous (gloo), barrier, max-over-ranks; no compute
-    import torch.distributed as dist
-    from nbmf_mm_amd import _hip
-
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nbmf_mm_amd import _dist, _hip, _rendezvous
+    group = _rendezvous.init_from_env()                 # plumbing only: handles / ids, barriers, max-over-ranks
 
     M, N, K = (args.M * world if args.weak else args.M), args.N, args.K
     masked = not args.no_mask
-    from nbmf_mm_amd import _dist
     r0, r1 = _dist.shard_bounds(M, world, rank)
 
     W_full, H0 = init_factors(M, N, K, args.seed)
-    # one rank = one GPU; if the launcher has narrowed every rank's view to its own card, that card is device 0
+    # one rank = one GPU.  A launcher may have narrowed every rank's view to its own card (then that card is
+    # device 0); anything in between -- several cards visible but fewer than ranks -- would silently stack ranks
+    # on one GPU, so it is refused.
     n_visible = _hip.device_count()
-    dev_index = 0 if (args.share_gpu or local_rank >= n_visible) else local_rank
+    if args.share_gpu or n_visible == 1:
+        dev_index = 0
+    elif local_rank < n_visible:
+        dev_index = local_rank
+    else:
+        raise SystemExit(f"LOCAL_RANK={local_rank} but only {n_visible} GPUs are visible to this rank "
+                         f"(need one per rank, or exactly one; --share-gpu stacks all ranks on device 0)")
     ctx = _hip.Context(r1 - r0, N, K, device=dev_index)
-    ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_DUCHI if args.projection == "duchi" else _hip.PROJ_NORMALIZE)
+    proj = _hip.PROJ_DUCHI if args.projection == "duchi" else _hip.PROJ_NORMALIZE
+    ctx.set_hyper(1.2, 1.2, 1e-8, proj)
     t_up = time.perf_counter()
     if args.device_data:
         if world > 1:
@@ -162,16 +228,18 @@ def main():
         bytes_up = X.nbytes + (Mk.nbytes if masked else 0)
         del X, Mk
     t_up = time.perf_counter() - t_up
-    ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
+
+    def reset():
+        ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
+
+    reset()
     transport, trials = "none", None
     if world > 1:
         if args.transport == "auto":
             # time a few iterations over each transport that attaches and keep the faster one (setup, untimed)
-            def reset():
-                ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
-            transport, trials = _dist.attach_fastest(ctx, dist, reset)
+            transport, trials = _dist.attach_fastest(ctx, group, reset)
         else:
-            transport = _dist.attach_comm(ctx, dist, args.transport)
+            transport = _dist.attach_comm(ctx, group, args.transport)
     elif args.force_comm:
         if args.transport == "peer":
             ctx.comm_init_peer(ctx.peer_export(0), 1, 0)
@@ -180,39 +248,42 @@ def main():
             ctx.comm_init(_hip.comm_unique_id(), 1, 0)
             transport = "rccl(1 rank)"
 
-    dev = dev_index
-    if torch.cuda.is_available():
-        torch.cuda.set_device(dev)
-
     def sync():
         ctx.synchronize()                       # the library's own stream
-        if torch.cuda.is_available():
-            torch.cuda.synchronize(dev)         # whole device (contract: barrier + torch.cuda.synchronize())
-        if world > 1:
-            dist.barrier()
+        _hip.device_synchronize(dev_index)      # whole device (hipDeviceSynchronize; contract: barrier + device sync)
+        group.barrier()
+
+    def timed(steps):
+        sync()
+        t0 = time.perf_counter()
+        losses, _ = ctx.run(steps, 0.0)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        sync()
+        return group.max_float(dt), losses
 
     if args.warmup > 0:
         ctx.run(args.warmup, 0.0)
     ctx.timing_enable(not args.no_events)
-    sync()
-    t0 = time.perf_counter()
-    losses, n_iter = ctx.run(args.steps, 0.0)
-    ctx.synchronize()
-    dt = time.perf_counter() - t0
-    sync()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, losses = timed(args.steps)
     tim = ctx.timing()
+    ctx.timing_enable(False)
     replicas_identical = None
+    devices = group.all_gather(dev_index)
     if world > 1:
         # the replicated factor must be the same bits on every rank whatever the transport did (outside the timed region)
         import hashlib
         digest = hashlib.sha256(ctx.get_factors()[1].tobytes()).hexdigest()
-        table = [None] * world
-        dist.all_gather_object(table, (digest, [float(v) for v in losses]))
+        table = group.all_gather((digest, [float(v) for v in losses]))
         replicas_identical = all(t == table[0] for t in table)
+    # the same steps under the other projection: "normalize" is the reference's own code path (_solver.py:54,57),
+    # "duchi" the README extension BASELINE configs[2] names -- same kernels, reported side by side
+    other = "normalize" if args.projection == "duchi" else "duchi"
+    ctx.set_hyper(1.2, 1.2, 1e-8, _hip.PROJ_NORMALIZE if other == "normalize" else _hip.PROJ_DUCHI)
+    reset()
+    if args.warmup > 0:
+        ctx.run(args.warmup, 0.0)
+    dt_other, losses_other = timed(args.steps)
     ctx.close()
 
     if rank == 0:
@@ -224,19 +295,23 @@ def main():
         flop_pass = 6.0 * m_loc * N * K
         achieved = flop_pass / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
         traffic, traffic_src = profiled_traffic(M, N, K, masked, world)
+        by_proj = {args.projection: its, other: args.steps / dt_other}
         out = {
             "metric": "MM-iterations/sec", "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic (generated on device)" if args.device_data else "synthetic",
             "final_nll_per_entry": float(losses[-1]), "replicas_identical": replicas_identical,
             "loss_monotone": bool(all(losses[i] <= losses[i - 1] + 1e-12 for i in range(1, len(losses)))),
+            "normalize_value": by_proj["normalize"], "duchi_value": by_proj["duchi"],
+            "final_nll_per_entry_" + other: float(losses_other[-1]),
             "config": {"workload": f"NBMF-MM fit, dense binary V {M}x{N} (float64 API, density 0.25), K={K}, "
                                    f"{'mask 90% observed' if masked else 'no mask'}, projection={args.projection}, "
                                    f"alpha=beta=1.2, tol=0 (BASELINE.json configs[2])",
                        "note": "projection=duchi is the README-only extension BASELINE configs[2] names (no reference code: "
-                               "property-tested); --projection normalize is the reference path, same kernels and the same "
-                               "speed to within 0.2 % (DESIGN.md 5)",
+                               "property-tested, parity unpinned); normalize_value is the reference's own path "
+                               "(_solver.py:54,57) timed in the same run on the same data",
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
+                       "devices": devices,
                        "transport_trials_s_per_5_iterations": trials,
                        "sharding": (f"rows/{world} ({transport}: " + ("reduce-scatter of 2*K*N+1 doubles fused with the H-update, K*N back"
                                                              if transport == "peer" else "all-reduce of 2*K*N+1 doubles"
@@ -250,22 +325,32 @@ def main():
                          "traffic_unit": "bytes per launch (PMC: (2*FETCH_SIZE + WRITE_SIZE) KiB; algorithmic: "
                                          "m*N code bytes + 2*chunks*K*N*8 slab bytes = %.3g)" % (m_loc * N + 2.0 * 16 * K * N * 8),
                          "hpass_ms": h_ms, "wpass_ms": w_ms,
+                         # the whole iteration against the same peak, two ways: EXECUTED MFMA flop (the W-pass runs one
+                         # back-product instead of two, SURVEY N4: 6 + 4 = 10*m*N*K) -- the utilisation figure -- and the
+                         # reference's ALGORITHMIC 12*m*N*K, which credits work that is not executed
+                         "executed_frac": (10.0 * m_loc * N * K * its / 1e12) / PEAK_FP64_MFMA_TFLOPS,
+                         "wpass_executed_frac": (4.0 * m_loc * N * K / (w_ms * 1e-3) / 1e12) / PEAK_FP64_MFMA_TFLOPS if w_ms > 0 else None,
                          "iteration_frac": (12.0 * m_loc * N * K * its / 1e12) / PEAK_FP64_MFMA_TFLOPS},
             "upload": {"seconds": t_up, "GBps_pcie_inclusive": (bytes_up / t_up / 1e9) if bytes_up else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             sample_rows = 2048
-            cdt, threads, closs = cpu_baseline(N, K, args.seed, masked, sample_rows, 3)
+            cdt, threads, closs = cpu_baseline(N, K, args.seed, masked, args.projection, sample_rows, 3)
             out["cpu_baseline"] = {"value": 1.0 / (cdt * M / sample_rows), "unit": "it/s", "cores": threads,
                                    "kind": "port",
                                    "sample": f"oracle/nbmf_oracle.py (NumPy+OpenBLAS) on the first {sample_rows} rows x {N} cols, "
                                              f"3 iterations after 1 warm-up = {cdt:.2f} s/it, scaled x{M // sample_rows} to {M} rows "
                                              f"(cost is linear in M)",
-                                   "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+                                   "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+                                   "host_ram_gb": host_ram_gb()}
             out["speedup_vs_cpu"] = its / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+            # parity number on the line: the HIP path on that same sample against the oracle
+            hloss = hip_sample_loss(N, K, args.seed, masked, args.projection, dev_index, sample_rows, 3)
+            out["parity"] = {"rel_nll_vs_oracle": abs(hloss - closs) / abs(closs), "hip_nll": hloss, "oracle_nll": closs,
+                             "sample": f"first {sample_rows} rows, same init, 4 iterations, projection={args.projection}",
+                             "tolerance": 1e-8}
+        print(json.dumps(out), flush=True)
+    group.close()
 
 
 if __name__ == "__main__":

@@ -60,7 +60,9 @@ int nbmf_device_count(int* count);
 int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out);
 int nbmf_destroy(nbmf_ctx* ctx);
 
-/* Hyper-parameters of nbmf_mm_solver (_solver.py:66-67,74) plus the projection extension. */
+/* Hyper-parameters of nbmf_mm_solver (_solver.py:66-67,74) plus the projection extension.  Any eps > 0 is
+ * accepted, as in the reference; below 1e-70 the binary path's log-likelihood takes a slower form that cannot
+ * underflow (one frexp per entry instead of one per 16x16 tile). */
 int nbmf_set_hyper(nbmf_ctx* ctx, double alpha, double beta, double eps, int projection);
 
 /* Upload the data matrix and optional mask (replaces the per-iteration Y*mask, Y.T*mask.T,
@@ -100,6 +102,15 @@ int nbmf_get_factors(nbmf_ctx* ctx, double* W_kxm, double* H_kxn);
  * relative-change stop rule (:169-174, checked on device).  losses must hold max_iter doubles;
  * *n_iter receives iteration+1 (:215).  Factors stay on the device (nbmf_get_factors). */
 int nbmf_run(nbmf_ctx* ctx, int max_iter, double tol, double* losses, int* n_iter);
+
+/* Progress reports while nbmf_run works (the `verbose` prints of _solver.py:165-166 need the losses as they
+ * arrive, not after the run): with a callback set, nbmf_run synchronises after every `every` iterations and
+ * hands over the losses that have become final since the last report -- iterations [first, first+count),
+ * `losses` pointing at the first of them.  The loss of iteration t is settled by the sweep of iteration t+1
+ * (SURVEY N3), so reports trail the device by one iteration; the values are those nbmf_run returns.
+ * fn == NULL (the default) switches reporting off: no intermediate synchronisation. */
+typedef void (*nbmf_progress_fn)(void* user, int first, int count, const double* losses);
+int nbmf_set_progress(nbmf_ctx* ctx, nbmf_progress_fn fn, void* user, int every);
 
 /* n_steps repetitions of the simplex-factor update with the Beta factor frozen: the loop body of
  * NBMFMM.transform, _base.py:178-193 (always "normalize", eps as set by nbmf_set_hyper). */
@@ -166,6 +177,9 @@ int nbmf_timing_enable(nbmf_ctx* ctx, int enable);
 /* ms summed over launches since enable, and launch counts; any pointer may be NULL. */
 int nbmf_timing_get(nbmf_ctx* ctx, double* hpass_ms, int* hpass_launches, double* wpass_ms, int* wpass_launches);
 int nbmf_synchronize(nbmf_ctx* ctx);
+/* hipDeviceSynchronize() on `device`: everything queued on that GPU by this process has finished (bench.py
+ * brackets its timed region with it). */
+int nbmf_device_synchronize(int device);
 
 /* Self-test hook used by the GPU tests: applies one of the pass kernel's scalar device routines to n
  * caller-supplied values (op 0: Newton reciprocal used on the binary path; op 1: the natural logarithm

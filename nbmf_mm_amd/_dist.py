@@ -5,19 +5,22 @@ Per iteration the only exchange is ONE sum over ranks of the H-step products [P1
 (2*K*N+1 doubles) on the library's own stream: its own peer kernels over xGMI, or RCCL.  The reference has
 no distributed counterpart; arithmetic differs from the single-GPU run by summation order only.
 
-torch.distributed (gloo) is used for rendezvous only: broadcasting the 128-byte RCCL id, barriers,
-and — in the tests / as a fallback transport — a host-mediated all-reduce.
-
-Load order: the PyTorch wheel bundles a private ROCm runtime; import torch BEFORE the first
-``nbmf_mm_amd`` context is created (callers of this module do, since they pass ``torch.distributed``
-in), otherwise RCCL resolves the HSA runtime to torch's uninitialised copy and reports "no
-ROCm-capable device".
+The ranks meet through a ``group`` object (``nbmf_mm_amd._rendezvous``: standard library only -- it moves the
+128-byte RCCL id or the HIP-IPC handle blocks, agreement flags and a max over ranks; ``init_from_env()`` reads
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as a launcher sets them).  Anything with the same small interface
+(``world``, ``rank``, ``all_gather``, ``broadcast``, ``barrier``, ``all_reduce``, ``agree``, ``max_float``)
+works; the tests wrap PyTorch's gloo backend that way.  Nothing here imports PyTorch.
 """
 from __future__ import annotations
 
 import numpy as np
 
 from . import _hip
+
+# a transport that cannot serve this job says so with NBMFHipError or -- for capability limits such as "at most
+# 16 ranks" or "too few columns to slice" (NBMF_ERR_ARG) -- ValueError; either way the ranks must still vote
+_REFUSED = (_hip.NBMFHipError, ValueError)
+
 
 def shard_bounds(M: int, world: int, rank: int):
     """Contiguous, balanced row range [r0, r1) of rank `rank` (each context pads its own shard)."""
@@ -43,48 +46,39 @@ def global_init(M, N, K, random_state, W_init=None, H_init=None):
     return np.ascontiguousarray(W), np.ascontiguousarray(H_init, dtype=np.float64)
 
 
-def attach_comm(ctx, dist, transport="auto", shard_axis=0):
-    """Join `ctx` to the job described by the initialised torch.distributed module `dist`.
+def attach_comm(ctx, group, transport="auto", shard_axis=0):
+    """Join `ctx` to the job described by ``group`` (see the module docstring).
 
     transport "peer": the library's own exchange kernels over xGMI (HIP-IPC mapped arenas; the H-update is
                       fused into a reduce-scatter).  One process per rank.
     transport "rccl": RCCL all-reduce on the library's stream ("rccl2": in two column panels, the second
                       overlapped with compute; rows split only).
-    transport "host": all-reduce through pinned host memory and `dist` (tests, rehearsal on one GPU).
-    transport "auto": peer, else RCCL, else host -- after each attempt the ranks agree (one all-reduce of a
-                      flag over `dist`) whether it worked everywhere, so the job never splits.
+    transport "host": all-reduce through pinned host memory and ``group`` (tests, rehearsal on one GPU).
+    transport "auto": peer, else RCCL, else host -- after each attempt the ranks agree (one exchange of a flag
+                      over ``group``) whether it worked everywhere, so the job never splits.
     Returns the transport used.
     """
-    import torch
-    world, rank = dist.get_world_size(), dist.get_rank()
-
-    def everyone(ok):
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return bool(flag.item())
+    world, rank = group.world, group.rank
 
     def host():
-        def allreduce(arr):
-            dist.all_reduce(torch.from_numpy(arr), op=dist.ReduceOp.SUM)
-        ctx.comm_init_host(allreduce, world, rank, shard_axis)
+        ctx.comm_init_host(lambda arr: group.all_reduce(arr, "sum"), world, rank, shard_axis)
         return "host"
 
     def peer():
         handle, err = None, None
         try:
             handle = ctx.peer_export(shard_axis)
-        except _hip.NBMFHipError as e:
+        except _REFUSED as e:
             err = str(e)
-        table = [None] * world
-        dist.all_gather_object(table, handle)
+        table = group.all_gather(handle)
         if any(h is None for h in table):
             return None, err or "another rank could not export its arena"
         try:
             ctx.comm_init_peer(b"".join(table), world, rank, shard_axis)
             ok = True
-        except _hip.NBMFHipError as e:
+        except _REFUSED as e:
             ok, err = False, str(e)
-        if everyone(ok):
+        if group.agree(ok):
             return "peer", None
         if ok:
             ctx.comm_detach()
@@ -95,18 +89,17 @@ def attach_comm(ctx, dist, transport="auto", shard_axis=0):
         if rank == 0:
             try:
                 uid = _hip.comm_unique_id()
-            except _hip.NBMFHipError as e:       # librccl could not be loaded
+            except _REFUSED as e:                # librccl could not be loaded
                 err = str(e)
-        box = [uid]
-        dist.broadcast_object_list(box, src=0)
-        if box[0] is None:
+        uid = group.broadcast(uid, src=0)
+        if uid is None:
             return None, f"RCCL unavailable on rank 0: {err}"
         try:
-            ctx.comm_init(box[0], world, rank, shard_axis)
+            ctx.comm_init(uid, world, rank, shard_axis)
             ok = True
-        except _hip.NBMFHipError as e:
+        except _REFUSED as e:
             ok, err = False, str(e)
-        if everyone(ok):
+        if group.agree(ok):
             return "rccl", None
         if ok:
             ctx.comm_detach()
@@ -120,7 +113,7 @@ def attach_comm(ctx, dist, transport="auto", shard_axis=0):
         old = os.environ.get("NBMF_OVERLAP")
         os.environ["NBMF_OVERLAP"] = "1"
         try:
-            attach_comm(ctx, dist, "rccl", shard_axis)
+            attach_comm(ctx, group, "rccl", shard_axis)
         finally:
             if old is None:
                 del os.environ["NBMF_OVERLAP"]
@@ -141,7 +134,7 @@ def attach_comm(ctx, dist, transport="auto", shard_axis=0):
     return host()
 
 
-def attach_fastest(ctx, dist, reset, shard_axis=0, candidates=("peer", "rccl"), iters=5):
+def attach_fastest(ctx, group, reset, shard_axis=0, candidates=("peer", "rccl"), iters=5):
     """Attach whichever of ``candidates`` runs the iteration fastest on THIS machine: each one that attaches on
     every rank is timed over ``iters`` iterations (max over ranks) and detached again; the winner is attached
     for good (the host transport if none attaches).  ``reset()`` must restore the factors (``ctx.set_factors``)
@@ -149,41 +142,38 @@ def attach_fastest(ctx, dist, reset, shard_axis=0, candidates=("peer", "rccl"), 
     ("rccl2" may be added to ``candidates``; it is not a default because it keeps two collectives of one
     communicator in flight on two streams, which has only been exercised with a single rank.)"""
     import time
-    import torch
     timings = {}
     for name in candidates:
         try:
-            attach_comm(ctx, dist, name, shard_axis)
-        except _hip.NBMFHipError:
+            attach_comm(ctx, group, name, shard_axis)
+        except _REFUSED:
             continue                                  # refused on some rank: every rank got the same answer
         try:
             reset()
             ctx.run(2, 0.0)
             ctx.synchronize()
-            dist.barrier()
+            group.barrier()
             t0 = time.perf_counter()
             ctx.run(int(iters), 0.0)
             ctx.synchronize()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-            ok = 1
-        except _hip.NBMFHipError:
-            t, ok = torch.tensor([float("inf")], dtype=torch.float64), 0
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            t, ok = time.perf_counter() - t0, True
+        except _REFUSED:
+            t, ok = float("inf"), False
+        t = group.max_float(t)
+        ok = group.agree(ok)
         ctx.comm_detach()
-        if flag.item():
-            timings[name] = float(t.item())
+        if ok:
+            timings[name] = t
     if timings:
         best = min(timings, key=timings.get)
-        attach_comm(ctx, dist, best, shard_axis)
+        attach_comm(ctx, group, best, shard_axis)
     else:
-        best = attach_comm(ctx, dist, "host", shard_axis)
+        best = attach_comm(ctx, group, "host", shard_axis)
     reset()
     return best, timings
 
 
-def fit_row_sharded(Y_local, M_global, r0, n_components, dist, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
+def fit_row_sharded(Y_local, M_global, r0, n_components, group, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
                     W_init=None, H_init=None, mask_local=None, random_state=None, eps=1e-8,
                     projection="normalize", device=0, transport="auto"):
     """beta-dir fit of the global (M_global x N) matrix whose rows [r0, r0+len(Y_local)) this rank
@@ -198,13 +188,13 @@ def fit_row_sharded(Y_local, M_global, r0, n_components, dist, max_iter=500, tol
         ctx.set_hyper(alpha, beta, eps, _projection_code(projection))
         upload_any(ctx, Y_local, mask_local)
         ctx.set_factors(np.ascontiguousarray(W[:, r0:r0 + m_loc]), H)
-        attach_comm(ctx, dist, transport)
+        attach_comm(ctx, group, transport)
         losses, n_iter = ctx.run(int(max_iter), float(tol))
         Wk, Hk = ctx.get_factors()
     return Wk.T, Hk, [float(v) for v in losses], n_iter
 
 
-def fit_sharded(V_local, global_shape, offset, n_components, dist, orientation="beta-dir", shard="rows",
+def fit_sharded(V_local, global_shape, offset, n_components, group, orientation="beta-dir", shard="rows",
                 max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None, H_init=None, mask_local=None,
                 random_state=None, eps=1e-8, projection="normalize", device=0, transport="auto"):
     """Sharded fit in the user's orientation, V split over the ranks by ``shard`` = "rows"
@@ -244,31 +234,29 @@ def fit_sharded(V_local, global_shape, offset, n_components, dist, orientation="
         ctx.set_hyper(alpha, beta, eps, _projection_code(projection))
         upload_any(ctx, V_local, mask_local, transposed=transposed)    # the pack applies the transpose
         ctx.set_factors(np.ascontiguousarray(W0), np.ascontiguousarray(H0))
-        attach_comm(ctx, dist, transport, shard_axis=axis)
+        attach_comm(ctx, group, transport, shard_axis=axis)
         losses, n_iter = ctx.run(int(max_iter), float(tol))
         Wk, Hk = ctx.get_factors()
     W_out, H_out = (Hk.T, Wk) if transposed else (Wk.T, Hk)           # un-transpose, _solver.py:178-184
     return W_out, H_out, [float(v) for v in losses], n_iter
 
 
-def fit_restarts(V, n_components, dist, n_init, random_state=0, device=0, **solver_kwargs):
+def fit_restarts(V, n_components, group, n_init, random_state=0, device=0, **solver_kwargs):
     """``n_init`` independent restarts spread over the ranks (replicas: every rank holds all of V and
     runs restarts rank, rank+world, ... with seeds random_state + i); the best final loss wins and its
     factors are broadcast.  Returns ``(W, H, losses, n_iter, best_index)`` on every rank."""
     from ._solver import nbmf_mm_solver
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = group.world, group.rank
     best = None
     for i in range(rank, int(n_init), world):
         res = nbmf_mm_solver(V, n_components, random_state=random_state + i, device=device, **solver_kwargs)
         if best is None or res[2][-1] < best[1][2][-1]:
             best = (i, res)
     mine = (float("inf"), -1) if best is None else (float(best[1][2][-1]), best[0])
-    table = [None] * world
-    dist.all_gather_object(table, mine)
+    table = group.all_gather(mine)
     win_rank = min(range(world), key=lambda r: (table[r][0], table[r][1]))
-    payload = [None]
+    payload = None
     if rank == win_rank:
         _, (W, H, losses, _, n_iter) = best
-        payload = [(W, H, losses, n_iter, best[0])]
-    dist.broadcast_object_list(payload, src=win_rank)
-    return payload[0]
+        payload = (W, H, losses, n_iter, best[0])
+    return group.broadcast(payload, src=win_rank)

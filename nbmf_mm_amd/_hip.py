@@ -33,11 +33,14 @@ SYMBOLS = [
     "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_loglik", "nbmf_loglik_strict", "nbmf_comm_unique_id", "nbmf_comm_init",
     "nbmf_comm_init_host", "nbmf_peer_export", "nbmf_comm_init_peer", "nbmf_comm_detach",
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
+    "nbmf_set_progress", "nbmf_device_synchronize",
 ]
 
 
 #: int fn(void* user, double* buf, int64 count) -- in-place sum over ranks on a host buffer
 HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, POINTER(c_double), c_int64)
+#: void fn(void* user, int first, int count, const double* losses) -- nbmf_set_progress
+PROGRESS_FN = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_int, POINTER(c_double))
 
 
 class NBMFHipError(RuntimeError):
@@ -51,6 +54,31 @@ def library_path() -> str:
 _lib = None
 
 
+def _autobuild(path):
+    """Build the library once if the toolchain is here.  Several ranks may arrive together from a fresh
+    checkout: the build is serialised by a file lock, written under a temporary name and renamed into place,
+    so nobody ever maps a half-written file; a failed build reports the compiler's own message."""
+    import fcntl
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+    if not (shutil.which("make") and hipcc):
+        return
+    with open(path + ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if os.path.exists(path):            # another rank built it while this one waited
+            return
+        tmp = f"{path}.tmp.{os.getpid()}"
+        r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), f"OUT={tmp}", f"HIPCC={hipcc}"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode == 0 and os.path.exists(tmp):
+            os.replace(tmp, path)
+        else:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise NBMFHipError(f"building {path} failed:\n{r.stdout[-2000:]}")
+
+
 def load():
     """Load libnbmf_hip.so (built by nbmf_mm_amd/csrc/Makefile or __graft_entry__.build())."""
     global _lib
@@ -58,12 +86,7 @@ def load():
         return _lib
     path = library_path()
     if not os.path.exists(path) and "NBMF_HIP_LIBRARY" not in os.environ and not os.environ.get("NBMF_NO_AUTOBUILD"):
-        # a source checkout without the built artefact: build it once if the toolchain is here
-        import shutil
-        import subprocess
-        if shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
-            subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], check=False,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _autobuild(path)                    # a source checkout without the built artefact
     if not os.path.exists(path):
         raise NBMFHipError(
             f"{path} not found: build it with `make -C nbmf_mm_amd/csrc` (needs hipcc); "
@@ -96,6 +119,8 @@ def load():
     lib.nbmf_timing_enable.argtypes = [c_void_p, c_int]
     lib.nbmf_timing_get.argtypes = [c_void_p, dp, POINTER(c_int), dp, POINTER(c_int)]
     lib.nbmf_synchronize.argtypes = [c_void_p]
+    lib.nbmf_set_progress.argtypes = [c_void_p, PROGRESS_FN, c_void_p, c_int]
+    lib.nbmf_device_synchronize.argtypes = [c_int]
     lib.nbmf_selftest_unary.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p]
     for name in SYMBOLS:
         if name != "nbmf_last_error":
@@ -301,6 +326,27 @@ class Context:
     def synchronize(self):
         _check(self._lib.nbmf_synchronize(self._h))
 
+    def set_progress(self, callback=None, every=10):
+        """``callback(first, losses)`` is called from inside :meth:`run` with the losses of iterations
+        ``first, first+1, ...`` as they become final (every ``every`` iterations); None switches it off."""
+        if callback is None:
+            self._progress_cb = None
+            _check(self._lib.nbmf_set_progress(self._h, PROGRESS_FN(), None, 0))
+            return
+
+        def _cb(_user, first, count, ptr):
+            try:
+                callback(int(first), [ptr[i] for i in range(int(count))])
+            except Exception:      # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+        self._progress_cb = PROGRESS_FN(_cb)             # keep alive as long as the context
+        _check(self._lib.nbmf_set_progress(self._h, self._progress_cb, None, int(every)))
+
+
+def device_synchronize(device=0):
+    _check(load().nbmf_device_synchronize(int(device)))
+
 
 def comm_unique_id() -> bytes:
     buf = ctypes.create_string_buffer(128)
@@ -317,16 +363,20 @@ def selftest_unary(op, x, device=0):
     return out
 
 
-def synthetic_reference(m, n, seed, density=0.25, observed=1.0):
+def synthetic_reference(m, n, seed, density=0.25, observed=1.0, rows=None, cols=None):
     """NumPy regeneration of ``Context.generate`` (same splitmix64 hash of (seed, i*n + j)): returns
-    (Y float64 m x n, mask bool m x n).  For the tests; O(m*n) host memory."""
+    (Y float64, mask bool) of the m x n matrix, or of its sub-matrix ``[rows][:, cols]`` when index
+    arrays are given (entries are hashed independently, so a slice costs only its own size).
+    For the tests; O(rows * cols) host memory."""
     def mix(x):
         x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
         x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         return x ^ (x >> np.uint64(31))
+    ri = np.arange(m, dtype=np.uint64) if rows is None else np.asarray(rows, dtype=np.uint64)
+    ci = np.arange(n, dtype=np.uint64) if cols is None else np.asarray(cols, dtype=np.uint64)
     with np.errstate(over="ignore"):
-        idx = np.arange(m * n, dtype=np.uint64).reshape(m, n)
+        idx = ri[:, None] * np.uint64(n) + ci[None, :]
         base = np.uint64(seed) * np.uint64(0x100000001B3) + idx
         u = (mix(base) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
         v = (mix(base ^ np.uint64(0xD6E8FEB86659FD93)) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)

@@ -97,17 +97,21 @@ def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
         if _ctx_hook is not None:
             _ctx_hook(ctx)
         ctx.set_factors(W, H)
+        if verbose > 0:
+            # the reference prints inside its loop (:165-166): the library reports the losses every ten
+            # iterations while it runs (one iteration behind the device, see nbmf_set_progress)
+            def _report(first, values):
+                for it, loss in enumerate(values, start=first):
+                    if it % 10 == 0:
+                        print(f"Iter {it:4d}: Loss = {loss:.6f}", flush=True)
+            ctx.set_progress(_report, every=10)
         losses, n_iter = ctx.run(int(max_iter), float(tol))
         Wk, Hk = ctx.get_factors()
 
     losses = [float(v) for v in losses]
-    if verbose > 0:                                    # same text as :165-166,172-173 (printed after the run)
-        for it, loss in enumerate(losses):
-            if it % 10 == 0:
-                print(f"Iter {it:4d}: Loss = {loss:.6f}")
-        if n_iter < int(max_iter) or (n_iter > 1 and losses[-2] != 0 and
-                                      abs(losses[-2] - losses[-1]) / abs(losses[-2]) < tol):
-            print(f"Converged at iteration {n_iter - 1}")
+    if verbose > 0 and (n_iter < int(max_iter) or (n_iter > 1 and losses[-2] != 0 and
+                                                   abs(losses[-2] - losses[-1]) / abs(losses[-2]) < tol)):
+        print(f"Converged at iteration {n_iter - 1}")   # :172-173
 
     W_final, H_final = Wk.T, Hk                        # :178-179
     if transposed:

@@ -294,6 +294,10 @@ struct nbmf_ctx {
   long long offHX = 0, offPR = 0, offSC = 0, x_doubles = 0;
   long long sl_c0 = 0, sl_wp = 0;   // axis 0: the column slice of H this rank updates
   double *Pbuf_own = nullptr, *sbuf_own = nullptr, *Qbuf_own = nullptr;   // the private buffers while the arena stands in
+  // progress reports out of nbmf_run (nbmf_set_progress)
+  nbmf_progress_fn progress = nullptr;
+  void* progress_user = nullptr;
+  int progress_every = 0;
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;   // pairs
@@ -321,13 +325,34 @@ Rccl g_rccl;
 
 int load_rccl() {
   if (g_rccl.lib) return NBMF_OK;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-  void* lib = nullptr;
-  for (const char* nm : names) {
-    lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-    if (lib) break;
+  // Which librccl: the one that belongs to the HIP runtime THIS library is linked against (the file next to
+  // that libamdhip64), not whatever a plain soname lookup finds first -- a PyTorch wheel in the same process
+  // brings its own, older copy bound to its own runtime.  NBMF_RCCL_LIBRARY overrides; the soname is the last
+  // resort.
+  std::vector<std::string> names;
+  if (const char* e = getenv("NBMF_RCCL_LIBRARY")) names.push_back(e);
+  Dl_info info;
+  if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) {
+      dir.resize(slash + 1);
+      names.push_back(dir + "librccl.so.1");
+      names.push_back(dir + "librccl.so");
+    }
   }
-  if (!lib) return fail(NBMF_ERR_COMM, "cannot load librccl: %s", dlerror());
+  for (const char* nm : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) names.push_back(nm);
+  void* lib = nullptr;
+  std::string tried;
+  for (const std::string& nm : names) {
+    lib = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (lib) {
+      if (getenv("NBMF_DEBUG")) fprintf(stderr, "[nbmf] RCCL: %s\n", nm.c_str());
+      break;
+    }
+    tried += nm + " ";
+  }
+  if (!lib) return fail(NBMF_ERR_COMM, "cannot load librccl (tried %s): %s", tried.c_str(), dlerror());
   g_rccl.GetUniqueId = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
   g_rccl.CommInitRank = (int (*)(void**, int, Uid, int))dlsym(lib, "ncclCommInitRank");
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
@@ -653,6 +678,8 @@ int enqueue_theta(nbmf_ctx* c, int image) {
     a.chunk_start = image == 0 ? c->cstartH : c->cstartW;
     a.C_alloc = image == 0 ? c->nA : c->mA;
     a.eps = c->eps;
+    a.tiny_eps = c->eps < 1e-70;
+  a.tiny_eps = c->eps < 1e-70;
     HIPCHK(launch_theta(a, image == 0 ? c->chunksH : c->chunksW, c->stream));
   }
   return NBMF_OK;
@@ -678,6 +705,8 @@ int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int cli
     a.chunk_start = c->cstartH;
     a.C_alloc = c->nA;
     a.eps = c->eps;
+    a.tiny_eps = c->eps < 1e-70;
+  a.tiny_eps = c->eps < 1e-70;
     a.strict = strict;
     a.clip = clip;
     a.theta = c->theta;
@@ -714,6 +743,7 @@ int enqueue_h_pass(nbmf_ctx* c) {
   a.chunk_start = c->cstartH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
+  a.tiny_eps = c->eps < 1e-70;
   {
     EvScope ev(c, 0);
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
@@ -746,6 +776,7 @@ int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0) {
   a.chunk_start = c->cstartH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
+  a.tiny_eps = c->eps < 1e-70;
   a.strict = strict;
   a.clip = clip;
   HIPCHK(launch_pass<MODE_L>(c->KB, c->data_kind, a, c->chunksH, c->stream));
@@ -817,6 +848,7 @@ PassArgs w_pass_args(nbmf_ctx* c) {
   a.chunk_start = c->cstartW;
   a.C_alloc = c->mA;
   a.eps = c->eps;
+  a.tiny_eps = c->eps < 1e-70;
   return a;
 }
 
@@ -891,6 +923,7 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   a.chunk_start = c->cstartH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
+  a.tiny_eps = c->eps < 1e-70;
   {
     EvScope ev(c, 0);
     if (c->KS > 1) {
@@ -969,6 +1002,7 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
   a.chunk_start = c->cstartH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
+  a.tiny_eps = c->eps < 1e-70;
   {
     EvScope ev(c, 0);
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, s0));
@@ -1314,6 +1348,7 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   if (!c || !x) return fail(NBMF_ERR_ARG, "null context or data");
   if (mask_kind != NBMF_MASK_NONE && !mask) return fail(NBMF_ERR_ARG, "mask_kind set but mask is NULL");
   if (!mask) mask_kind = NBMF_MASK_NONE;
+  if (is_sharded(c)) return fail(NBMF_ERR_STATE, "upload before attaching a communicator");
   if (int rc = set_device(c)) return rc;
   const int64_t U = transposed ? c->n : c->m, V = transposed ? c->m : c->n;
   if (ldx < V || (mask && ldmask < V)) return fail(NBMF_ERR_ARG, "leading dimension smaller than the row length");
@@ -1619,7 +1654,18 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
 
   // Timeline (N3 of SURVEY Appendix A): the H-pass of iteration t also yields the log-likelihood of
   // the factors after iteration t-1, so loss(t-1) and its stop test are settled before H-update(t).
-  const int batch = (tol > 0.0) ? 8 : max_iter;
+  const bool progress = c->progress && c->progress_every > 0;
+  const int batch = progress ? c->progress_every : (tol > 0.0) ? 8 : max_iter;
+  int reported = 0;   // losses already handed to the progress callback
+  std::vector<double> fresh;
+  auto report = [&](int n_final) -> int {
+    if (!progress || n_final <= reported) return NBMF_OK;
+    fresh.resize((size_t)(n_final - reported));
+    HIPCHK(hipMemcpy(fresh.data(), c->losses_d + reported, sizeof(double) * fresh.size(), hipMemcpyDeviceToHost));
+    c->progress(c->progress_user, reported, n_final - reported, fresh.data());
+    reported = n_final;
+    return NBMF_OK;
+  };
   int host_done = 0;
   int it = 0;
   // One iteration = five launches with identical arguments every time (the loss index is counted on the
@@ -1627,7 +1673,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   // (config 1, 100x500 K=6: 14.7k it/s replayed vs 16.5k it/s eager) -- tiny problems are bound by the
   // latency of the five dependent kernels, not by the host's launch rate -- so it is opt-in
   // (NBMF_USE_GRAPH=1), never used with a communicator or event timing.
-  const bool use_graph = getenv("NBMF_USE_GRAPH") && !is_sharded(c) && !c->timing && max_iter >= 8;
+  const bool use_graph = getenv("NBMF_USE_GRAPH") && !is_sharded(c) && !c->timing && !progress && max_iter >= 8;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   if (use_graph) {
@@ -1666,13 +1712,14 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
       if (int rc = enqueue_h_update(c)) return rc;
       if (int rc = enqueue_w_step(c, c->projection)) return rc;
     }
-    if (tol > 0.0 && it < max_iter) {
+    if ((tol > 0.0 || progress) && it < max_iter) {
       int fl[2];
       HIPCHK(hipMemcpyAsync(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       if (c->timing) timing_collect(c);
       if (int rc = peer_check(c)) return rc;
       host_done = fl[0];
+      if (int rc = report(fl[1])) return rc;
     }
   }
   if (!host_done) {
@@ -1686,6 +1733,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   if (int rc = peer_check(c)) return rc;
   const int nit = fl[1];
   if (nit < 1 || nit > max_iter) return fail(NBMF_ERR_STATE, "internal: device reported n_iter=%d", nit);
+  if (int rc = report(nit)) return rc;
   HIPCHK(hipMemcpy(losses, c->losses_d, sizeof(double) * (size_t)nit, hipMemcpyDeviceToHost));
   *n_iter = nit;
   return NBMF_OK;
@@ -1996,6 +2044,21 @@ int nbmf_timing_get(nbmf_ctx* c, double* hpass_ms, int* hpass_launches, double* 
   if (hpass_launches) *hpass_launches = c->t_n[0];
   if (wpass_ms) *wpass_ms = c->t_ms[1];
   if (wpass_launches) *wpass_launches = c->t_n[1];
+  return NBMF_OK;
+}
+
+int nbmf_set_progress(nbmf_ctx* c, nbmf_progress_fn fn, void* user, int every) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (fn && every < 1) return fail(NBMF_ERR_ARG, "every must be >= 1");
+  c->progress = fn;
+  c->progress_user = user;
+  c->progress_every = fn ? every : 0;
+  return NBMF_OK;
+}
+
+int nbmf_device_synchronize(int device) {
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipDeviceSynchronize());
   return NBMF_OK;
 }
 

@@ -2,7 +2,7 @@
 masked training followed by held-out perplexity over a grid of (alpha, beta) prior settings and/or
 component counts K.  The data matrix and each mask are packed onto the device ONCE per K; every grid
 point reuses them (`train_nbmf_mm`, :49-73; `compute_perplexity`, :40-47; the figure loops, :75-340).
-With a torch.distributed group the grid points are dealt round-robin over the ranks (one GPU each).
+With a process group (nbmf_mm_amd._rendezvous) the grid points are dealt round-robin over the ranks (one GPU each).
 """
 from __future__ import annotations
 
@@ -62,7 +62,7 @@ def _init(m, n, k, random_state):
 
 
 def perplexity_grid(Y, train_mask, eval_masks, n_components, alphas, betas, max_iter=500, tol=1e-5,
-                    random_state=12345, device=0, dist=None, concurrency=1):
+                    random_state=12345, device=0, group=None, concurrency=1):
     """Fit beta-dir NBMF-MM on `train_mask` for every (K, alpha, beta) and report held-out perplexities.
 
     eval_masks: dict name -> mask (e.g. {"val": val_mask, "test": test_mask}).
@@ -75,7 +75,7 @@ def perplexity_grid(Y, train_mask, eval_masks, n_components, alphas, betas, max_
     Y = np.asarray(Y, dtype=np.float64)
     Ks = [int(n_components)] if np.isscalar(n_components) else [int(k) for k in n_components]
     points = [(k, float(a), float(b)) for k in Ks for a in alphas for b in betas]
-    world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+    world, rank = (group.world, group.rank) if group is not None else (1, 0)
     mine = points[rank::world]
     args = (Y, train_mask, eval_masks, max_iter, tol, random_state, device)
     conc = max(1, min(int(concurrency), len(mine)))
@@ -86,8 +86,6 @@ def perplexity_grid(Y, train_mask, eval_masks, n_components, alphas, betas, max_
         parts = [sorted(mine)[i::conc] for i in range(conc)]
         with ThreadPoolExecutor(max_workers=conc) as pool:     # ctypes releases the GIL inside the library
             rows = [r for part in pool.map(lambda pts: _run_points(pts, *args), parts) for r in part]
-    if dist is not None and world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, rows)
-        rows = [r for part in gathered for r in part]
+    if group is not None and world > 1:
+        rows = [r for part in group.all_gather(rows) for r in part]
     return sorted(rows, key=lambda r: (r["K"], r["alpha"], r["beta"]))

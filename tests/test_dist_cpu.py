@@ -15,15 +15,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, kind):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
-    import torch
-    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from gloo_group import make_group
     from nbmf_mm_amd import _dist
     from oracle import sharded_oracle
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist = make_group(kind, rank, world, port)
     try:
         M, N, K = 301, 120, 7
         g = np.random.default_rng(11)
@@ -33,7 +33,7 @@ def _worker(rank, world, port, q):
         W, H = _dist.global_init(M, N, K, random_state=3)
 
         def allreduce(arr):
-            dist.all_reduce(torch.from_numpy(arr), op=dist.ReduceOp.SUM)
+            dist.all_reduce(arr, "sum")
 
         nobs = np.array([float(np.count_nonzero(mask[r0:r1]))])
         allreduce(nobs)
@@ -46,20 +46,20 @@ def _worker(rank, world, port, q):
         Wc, Hc, lc = sharded_oracle.sharded_solve_cols(Y[:, c0:c1], mask[:, c0:c1], W, H[:, c0:c1], 1.2, 1.3, nobs2[0], N,
                                                        allreduce, max_iter=25)
         # rendezvous object broadcast as attach_comm does it
-        uid = [bytes(range(128)) if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        q.put((rank, r0, r1, Wl, Hn, losses, uid[0], (c0, c1, Wc, Hc, lc)))
+        uid = dist.broadcast(bytes(range(128)) if rank == 0 else None, src=0)
+        q.put((rank, r0, r1, Wl, Hn, losses, uid, (c0, c1, Wc, Hc, lc)))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
-def test_sharded_iteration_equals_unsharded():
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("kind", ["gloo", "stdlib"])
+def test_sharded_iteration_equals_unsharded(kind):
+    import multiprocessing as mp
     from oracle import nbmf_oracle as orc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
@@ -131,6 +131,8 @@ class _StubCtx:
         if "peer" in self.fail:
             from nbmf_mm_amd import _hip
             raise _hip.NBMFHipError("peer transport self-test failed")
+        if "peer_arg" in self.fail:       # a capability limit: NBMF_ERR_ARG -> ValueError (_hip._check)
+            raise ValueError("the peer transport supports at most 16 ranks")
 
     def comm_init(self, uid, world, rank, axis):
         self.calls.append("rccl")
@@ -145,13 +147,14 @@ class _StubCtx:
         self.calls.append("detach")
 
 
-def _worker_negotiate(rank, world, port, q):
+def _worker_negotiate(rank, world, port, q, kind):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
-    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from gloo_group import make_group
     from nbmf_mm_amd import _dist, _hip
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist = make_group(kind, rank, world, port)
     _hip.comm_unique_id = lambda: bytes(128)          # no librccl call on the CPU box
     try:
         out = {}
@@ -164,6 +167,9 @@ def _worker_negotiate(rank, world, port, q):
         # no IPC on rank 0, RCCL init fails on rank 1: both end on the host transport
         c = _StubCtx((["export"] if rank == 0 else []) + (["rccl"] if rank == 1 else []))
         out["down_to_host"] = (_dist.attach_comm(c, dist, "auto"), c.calls)
+        # a capability limit (ValueError) on ONE rank only: still a vote, both fall back to RCCL together
+        c = _StubCtx(["peer_arg"] if rank == 0 else [])
+        out["capability_limit"] = (_dist.attach_comm(c, dist, "auto"), c.calls)
         # an explicit transport does not fall back: every rank raises
         c = _StubCtx(["peer"] if rank == 0 else [])
         try:
@@ -173,15 +179,16 @@ def _worker_negotiate(rank, world, port, q):
             out["explicit"] = ("raised", c.calls)
         q.put((rank, out))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
-def test_transport_negotiation_never_splits_the_job():
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("kind", ["gloo", "stdlib"])
+def test_transport_negotiation_never_splits_the_job(kind):
+    import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_negotiate, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_negotiate, args=(r, 2, port, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
     res = [o for _, o in sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])]
@@ -193,18 +200,21 @@ def test_transport_negotiation_never_splits_the_job():
     assert res[1]["peer_fails_on_1"] == ("rccl", ["export", "peer", "rccl"])
     assert res[0]["down_to_host"] == ("host", ["export", "rccl", "detach", "host"])
     assert res[1]["down_to_host"] == ("host", ["export", "rccl", "host"])
+    assert res[0]["capability_limit"] == ("rccl", ["export", "peer", "rccl"])
+    assert res[1]["capability_limit"] == ("rccl", ["export", "peer", "detach", "rccl"])
     assert res[0]["explicit"] == ("raised", ["export", "peer"])
     assert res[1]["explicit"] == ("raised", ["export", "peer", "detach"])
 
 
-def _worker_fastest(rank, world, port, q):
+def _worker_fastest(rank, world, port, q, kind):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import time
-    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from gloo_group import make_group
     from nbmf_mm_amd import _dist, _hip
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist = make_group(kind, rank, world, port)
     _hip.comm_unique_id = lambda: bytes(128)
 
     class Ctx(_StubCtx):
@@ -245,15 +255,16 @@ def _worker_fastest(rank, world, port, q):
         out["none"] = _dist.attach_fastest(c, dist, lambda: None, iters=2)[0], c.calls[-1]
         q.put((rank, out))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
-def test_attach_fastest_picks_by_the_slowest_rank():
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("kind", ["gloo", "stdlib"])
+def test_attach_fastest_picks_by_the_slowest_rank(kind):
+    import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_fastest, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_fastest, args=(r, 2, port, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
     res = [o for _, o in sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])]
@@ -268,3 +279,70 @@ def test_attach_fastest_picks_by_the_slowest_rank():
         assert r["peer_only"] == ("peer", "peer")
         assert r["none"] == ("host", "host")
     assert res[0]["slow_peer"][1] == res[1]["slow_peer"][1]  # the max over ranks is what every rank sees
+
+
+def _worker_env(rank, world, port, q, tcp):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if tcp:
+        os.environ["NBMF_RDZV_PORT"] = str(port)
+    else:
+        os.environ.pop("NBMF_RDZV_PORT", None)
+    from nbmf_mm_amd import _rendezvous
+    with _rendezvous.init_from_env(timeout=60) as g:
+        out = {"who": (g.rank, g.world)}
+        out["gather"] = g.all_gather({"rank": rank, "blob": bytes([rank]) * 128})
+        out["bcast"] = g.broadcast(np.arange(5) if rank == 1 else None, src=1)
+        big = np.full(1 << 20, float(rank + 1))                 # an 8 MiB payload (the host transport's size at c3)
+        g.all_reduce(big, "sum")
+        out["sum"] = (float(big[0]), float(big[-1]))
+        small = np.array([0.1 * (rank + 1), 1.0 / 3.0])
+        g.all_reduce(small, "sum")
+        out["bits"] = small.tobytes()                           # formed in rank order on every rank: same bits
+        out["agree"] = (g.agree(True), g.agree(rank == 0))
+        out["max"] = g.max_float(1.5 + rank)
+        g.barrier()
+    q.put((rank, out))
+
+
+@pytest.mark.parametrize("tcp", [False, True])
+def test_stdlib_rendezvous_from_env(tcp):
+    """The product's own group as a launcher's environment describes it: abstract Unix socket named after
+    MASTER_PORT (which the launcher itself may be listening on), or TCP with NBMF_RDZV_PORT."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    holder = None
+    if not tcp:                      # somebody else (torch.distributed.run's store) owns the TCP port itself
+        holder = socket.socket()
+        holder.bind(("127.0.0.1", port))
+        holder.listen(1)
+    world = 3
+    procs = [ctx.Process(target=_worker_env, args=(r, world, port, q, tcp)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [o for _, o in sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    if holder:
+        holder.close()
+    for r, o in enumerate(res):
+        assert o["who"] == (r, world)
+        assert [d["rank"] for d in o["gather"]] == [0, 1, 2] and o["gather"][2]["blob"] == b"\x02" * 128
+        np.testing.assert_array_equal(o["bcast"], np.arange(5))
+        assert o["sum"] == (6.0, 6.0)
+        assert o["agree"] == (True, False) and o["max"] == 3.5
+        assert o["bits"] == res[0]["bits"]
+
+
+def test_single_group_is_the_identity():
+    from nbmf_mm_amd import _rendezvous
+    os.environ.pop("WORLD_SIZE", None)
+    g = _rendezvous.init_from_env()
+    assert isinstance(g, _rendezvous.SingleGroup) and (g.rank, g.world) == (0, 1)
+    a = np.array([1.0, 2.0])
+    assert g.all_reduce(a) is a and g.all_gather(7) == [7] and g.broadcast("x") == "x" and g.agree(True) and g.max_float(2) == 2.0

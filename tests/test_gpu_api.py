@@ -179,3 +179,38 @@ def test_sparse_input_stays_sparse_and_matches_dense():
             NBMF(n_components=k, max_iter=2).fit(Xbad)
     finally:
         _hip.Context.upload_csr = orig
+
+
+def test_progress_reports_arrive_during_the_run():
+    """verbose's live prints (_solver.py:165-166) rest on nbmf_set_progress: every loss is reported exactly once,
+    in order, in several calls made from inside nbmf_run, with the values the run returns -- also when the stop
+    rule ends the run early -- and the run itself is unchanged by reporting."""
+    from nbmf_mm_amd import _hip
+    r = np.random.default_rng(3)
+    Y = (r.random((150, 220)) < 0.3).astype(np.float64)
+    W0 = r.uniform(0.1, 0.9, (7, 150))
+    W0 /= W0.sum(axis=0, keepdims=True)
+    H0 = r.uniform(0.1, 0.9, (7, 220))
+    for max_iter, tol in [(95, 0.0), (400, 1e-4)]:
+        with _hip.Context(150, 220, 7) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            ctx.upload(Y)
+            ctx.set_factors(W0, H0)
+            plain, n_plain = ctx.run(max_iter, tol)
+            Wp, Hp = ctx.get_factors()
+            calls = []
+            ctx.set_progress(lambda first, vals: calls.append((first, list(vals))), every=10)
+            ctx.set_factors(W0, H0)
+            losses, n_iter = ctx.run(max_iter, tol)
+            Wq, Hq = ctx.get_factors()
+            ctx.set_progress(None)
+            ctx.set_factors(W0, H0)
+            again, _ = ctx.run(max_iter, tol)
+        assert n_iter == n_plain and (tol == 0.0 or 5 < n_iter < max_iter)
+        np.testing.assert_array_equal(losses, plain)
+        np.testing.assert_array_equal(again, plain)
+        np.testing.assert_array_equal(Wq, Wp)
+        np.testing.assert_array_equal(Hq, Hp)
+        assert len(calls) >= n_iter // 10 and all(len(v) <= 11 for _, v in calls)
+        assert [f for f, _ in calls] == list(np.cumsum([0] + [len(v) for _, v in calls[:-1]]))
+        np.testing.assert_array_equal(np.concatenate([v for _, v in calls]), losses)

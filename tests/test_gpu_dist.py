@@ -30,9 +30,8 @@ def _worker_dirbeta_restarts(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
-    import torch.distributed as dist
-    from nbmf_mm_amd import _dist
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from nbmf_mm_amd import _dist, _rendezvous
+    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
     try:
         M, N, K, Y, mask = _problem()
         V, Vmask = Y[:300, :], mask[:300, :]                 # dir-beta on a 300 x 333 matrix, column shards
@@ -43,16 +42,15 @@ def _worker_dirbeta_restarts(rank, world, port, q):
         best = _dist.fit_restarts(V, 9, dist, n_init=3, random_state=10, device=0, max_iter=15, tol=0, mask=Vmask)
         q.put((rank, c0, c1, W, Hl, losses, best))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
 def _worker(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
-    import torch.distributed as dist
-    from nbmf_mm_amd import _dist
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from nbmf_mm_amd import _dist, _rendezvous
+    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
     try:
         M, N, K, Y, mask = _problem()
         r0, r1 = _dist.shard_bounds(M, world, rank)
@@ -60,11 +58,11 @@ def _worker(rank, world, port, q):
                                                       mask_local=mask[r0:r1], random_state=5, device=0, transport="host")
         q.put((rank, r0, r1, Wl, H, losses, n_iter))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
 def test_two_ranks_one_gpu_host_transport():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     from nbmf_mm_amd import nbmf_mm_solver
     from oracle import nbmf_oracle as orc
     ctx = mp.get_context("spawn")
@@ -138,7 +136,7 @@ def test_rccl_single_rank():
 
 
 def test_dir_beta_column_shards_and_parallel_restarts():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     from nbmf_mm_amd import nbmf_mm_solver
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -173,9 +171,8 @@ def _worker_axis1(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
-    import torch.distributed as dist
-    from nbmf_mm_amd import _dist
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from nbmf_mm_amd import _dist, _rendezvous
+    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
     try:
         M, N, K, Y, mask = _problem()
         V, Vmask = Y[:300, :], mask[:300, :]
@@ -192,11 +189,11 @@ def _worker_axis1(rank, world, port, q):
                                                      projection="duchi", device=0, transport="host")
         q.put((rank, out))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
 def test_column_split_of_the_internal_matrix():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     from nbmf_mm_amd import nbmf_mm_solver
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -231,7 +228,7 @@ def test_column_split_of_the_internal_matrix():
 
 def test_three_ranks_uneven_shards():
     """world = 3 (uneven 233/233/234 row shards, one GPU shared, host transport) against the single-process run."""
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     from nbmf_mm_amd import nbmf_mm_solver
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -265,9 +262,8 @@ def _worker_wide(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
-    import torch.distributed as dist
-    from nbmf_mm_amd import _dist
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from nbmf_mm_amd import _dist, _rendezvous
+    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
     try:
         M, N, K, Y, mask = _wide_problem()
         r0, r1 = _dist.shard_bounds(M, world, rank)
@@ -275,14 +271,14 @@ def _worker_wide(rank, world, port, q):
                                                       random_state=2, device=0, transport="host")
         q.put((rank, Wl, H, losses, n_iter))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
 def test_two_exchange_panels(capfd, monkeypatch):
     """The K x N exchange cut into two column panels (second panel's all-reduce overlapping the first
     panel's H-update and W-pass share): RCCL with one rank (two streams + events) and two ranks over the
     host transport, against the single-process run, stop rule included."""
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     from nbmf_mm_amd import _hip, _dist, nbmf_mm_solver
     M, N, K, Y, mask = _wide_problem()
     W1, H1, l1, _, n1 = nbmf_mm_solver(Y, K, max_iter=200, tol=1e-4, mask=mask, random_state=2)

@@ -32,9 +32,8 @@ def _setup(rank, world, port):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     os.environ.setdefault("NBMF_PEER_TIMEOUT_MS", "20000")
-    import torch.distributed as dist
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    return dist
+    from nbmf_mm_amd import _rendezvous
+    return _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
 
 
 def _worker_rows(rank, world, port, q):
@@ -49,11 +48,11 @@ def _worker_rows(rank, world, port, q):
                                               random_state=5, device=0, transport="peer", **kw)
         q.put((rank, r0, r1, out))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
 def _run(target, world, *extra):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -126,7 +125,7 @@ def _worker_axis1(rank, world, port, q):
         out["eval"] = (a, b, la, lb)
         q.put((rank, out))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
 def test_column_split_peer_transport():
@@ -170,8 +169,7 @@ def _worker_absent_peer(rank, world, port, q):
             ctx.set_hyper(1.2, 1.2)
             ctx.upload(Y[r0:r1], mask=mask[r0:r1])
             ctx.set_factors(np.ascontiguousarray(W[:, r0:r1]), H)
-            table = [None] * world
-            dist.all_gather_object(table, ctx.peer_export(0))
+            table = dist.all_gather(ctx.peer_export(0))
             t0 = time.perf_counter()
             msg = None
             if rank == 0:                       # rank 1 never attaches: rank 0 must give up, not hang
@@ -185,7 +183,7 @@ def _worker_absent_peer(rank, world, port, q):
             q.put((rank, msg, dt, n_iter))
         dist.barrier()
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
 def test_missing_rank_times_out_instead_of_hanging():
@@ -211,7 +209,7 @@ def _worker_k200(rank, world, port, q):
                                                   mask_local=Vmask[:, c0:c1], random_state=4, device=0, transport=tr)
         q.put((rank, out))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
 def test_sharded_more_than_128_components():
@@ -251,7 +249,7 @@ def _worker_sequence(rank, world, port, q):
                                          random_state=4, device=0, transport="peer"))
         q.put((rank, out))
     finally:
-        dist.destroy_process_group()
+        dist.close()
 
 
 def test_many_sharded_fits_in_one_process():
