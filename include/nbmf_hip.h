@@ -60,8 +60,8 @@ int nbmf_device_count(int* count);
 int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out);
 int nbmf_destroy(nbmf_ctx* ctx);
 
-/* Hyper-parameters of nbmf_mm_solver (_solver.py:66-67,74) plus the projection extension.  Any eps > 0 is
- * accepted, as in the reference; below 1e-70 the binary path's log-likelihood takes a slower form that cannot
+/* Hyper-parameters of nbmf_mm_solver (_solver.py:66-67,74) plus the projection extension.  Any positive
+ * normal eps is accepted; below 1e-70 the binary path's log-likelihood takes a slower form that cannot
  * underflow (one frexp per entry instead of one per 16x16 tile). */
 int nbmf_set_hyper(nbmf_ctx* ctx, double alpha, double beta, double eps, int projection);
 
@@ -184,7 +184,7 @@ int nbmf_device_synchronize(int device);
 /* Self-test hook used by the GPU tests: applies one of the pass kernel's scalar device routines to n
  * caller-supplied values (op 0: Newton reciprocal used on the binary path; op 1: the natural logarithm
  * of the general path; op 2: the general path's quotient, evaluated as (1 - 0.75 x) / x) so the host can
- * compare with IEEE 1/x, log(x) and the IEEE quotient. */
+ * compare with IEEE 1/x, log(x) and the IEEE quotient (accuracy contracts: tests/test_gpu_parity.py). */
 #define NBMF_SELFTEST_RCP 0
 #define NBMF_SELFTEST_LOG 1
 #define NBMF_SELFTEST_DIV 2

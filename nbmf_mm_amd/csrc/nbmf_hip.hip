@@ -139,30 +139,42 @@ __device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) {
   return __hiloint2double((int)hi, (int)lo);
 }
 
-// Natural logarithm for the general (real-valued / weighted) path: ~35 VALU instructions instead of the
-// ~75 of the library routine, which matters because f64 VALU work shares the pipe with the f64 MFMAs.
-// Classic reduction x = 2^k (1+f), sqrt(2)/2 <= 1+f < sqrt(2); s = f/(2+f); log(1+f) = f - f^2/2 +
-// s (f^2/2 + R(s^2)) with the degree-7 minimax R of Sun's fdlibm e_log.c (error < 1 ulp); the quotient
-// uses the Newton reciprocal above.  Non-positive, non-finite and subnormal arguments take the library
-// routine (same NaN / -inf results as NumPy).
-__device__ __forceinline__ double log_fast(double x) {
-  if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log(x);
-  int k;
-  double m = frexp(x, &k);                       // m in [0.5, 1)
-  const bool lo = m < 0.70710678118654752440;
-  m = lo ? m + m : m;
-  k = lo ? k - 1 : k;
-  const double f = m - 1.0;
-  const double s = f * rcp_nr(2.0 + f);
-  const double z = s * s;
-  const double w = z * z;
-  const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                                      2.857142874366239149e-01), 6.666666666666735130e-01);
-  const double R = t2 + t1;
-  const double hfsq = 0.5 * f * f;
-  const double dk = (double)k;
-  return dk * 6.93147180369123816490e-01 - ((hfsq - __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+// Natural logarithm for the general (real-valued / weighted) path, where two logarithms per entry feed the
+// loss and every VALU instruction adds to the f64 MFMA time: a 256-entry table in LDS plus a short series,
+// 13 VALU instructions and one ds_read_b128 (the library routine: ~75; the fdlibm-style routine this replaces: ~35).
+//   x = 2^e * m, m in [0.5, 1);  bin j = top 8 fraction bits of m;  table[j] = {c_j, -log(c_j)}, c_j = 1/(bin centre)
+//   r = m c_j - 1 (one FMA, |r| <= 2^-9);  log x = e ln2 - log c_j + log1p(r),  log1p to r^5/5 (next term 2^-56.6)
+// Absolute error <= 2.5e-16 + 1 ulp of the result (the table value and e ln2 are each rounded once): sums of
+// millions of such terms of size ~0.5 keep the loss well inside its 1e-10 tolerance.  GUARD: arguments that are
+// not positive normal numbers (1 - Theta + eps <= 0 needs factors off the simplex; eps is at least the smallest
+// normal number) take the library routine: same NaN / -inf as NumPy.
+// max(x, 0) with a NaN x giving 0 (v_max_f64 returns the operand that is a number): one instruction, where the
+// compiler's fmax adds a canonicalising one in front for a value it has loaded from memory.
+__device__ __forceinline__ double max0(double x) {
+  double r;
+  __asm__("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(x));
+  return r;
+}
+constexpr int LOG_TABLE_BYTES = 256 * 16;
+__device__ __forceinline__ void log_table_fill(double2* tab /* LDS, 256 entries; threads 0..255 */) {
+  if (threadIdx.x < 256) {
+    const double c = 1.0 / (0.5 + ((double)threadIdx.x + 0.5) * (1.0 / 512.0));
+    tab[threadIdx.x] = double2{c, -log(c)};
+  }
+}
+template <bool GUARD>
+__device__ __forceinline__ double log_tab(double x, const double2* tab) {
+  if (GUARD && __builtin_expect(!__builtin_amdgcn_class(x, 0x100), 0)) return log(x);   // not a positive normal number
+  const uint32_t hi = (uint32_t)__double2hiint(x);
+  const double m = mk_double((uint32_t)__double2loint(x), (hi & 0x000FFFFFu) | 0x3FE00000u);
+  const double2 e = tab[(hi >> 12) & 0xFFu];
+  const double r = __builtin_fma(m, e.x, -1.0);
+  double p = __builtin_fma(r, 0.2, -0.25);
+  p = __builtin_fma(r, p, 0.33333333333333331483);
+  p = __builtin_fma(r, p, -0.5);
+  p = __builtin_fma(r, p, 1.0);
+  const double k = (double)__builtin_amdgcn_frexp_exp(x);
+  return __builtin_fma(r, p, __builtin_fma(k, 0.69314718055994530942, e.y));
 }
 
 // Per-lane selects on a 64-bit wave mask, written out because the pass kernels are VALU-issue bound next to
@@ -443,7 +455,7 @@ void arena_release(ArenaSlot* a) {
 template <int KB, int DATA, int MODE, int TH = 0>
 hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
   dim3 grid(a.Cb / WG_WAVES, chunks);
-  constexpr int lds_bytes = (NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES;
+  constexpr int lds_bytes = ((NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES) + (DATA != DATA_BIN ? LOG_TABLE_BYTES : 0);
   if (lds_bytes > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
@@ -513,7 +525,7 @@ template <int MODE>
 int resident_per_cu(int KB, int data_kind) {
   int n = 0;
   const void* f = pass_ptr<MODE>(KB, data_kind);
-  const int lds_bytes = (NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES;
+  const int lds_bytes = ((NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES) + (data_kind != DATA_BIN ? LOG_TABLE_BYTES : 0);
   if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64 * WG_WAVES, lds_bytes) != hipSuccess || n < 1) n = 2;
   return std::min(n, 8);
 }
@@ -622,13 +634,15 @@ int all_reduce_inplace(nbmf_ctx* c, double* p, size_t count, hipStream_t st = nu
 
 inline bool is_sharded(const nbmf_ctx* c) { return c->comm || c->host_reduce || c->peer; }
 
-// Binary path: the H-pass multiplies every entry of the padded mA x nA grid into the likelihood
-// product; a pad entry has Theta == 0 and is not an observed one, so it contributes exactly
-// fl(fl(1-0)+eps) = 1+eps.  Their total is removed before the loss is assembled (and before any
-// all-reduce).
-double ll_pad_of(const nbmf_ctx* c) {
+// Every sweep over image A takes in all entries of the padded mA x nA grid.  A pad entry has Theta == 0 and
+// counts as "not an observed one" (binary path: code 0; general path: y = 0, weight 0), so it contributes
+// exactly log(fl(fl(1-0)+eps)) = log(1+eps) to the likelihood; their total is removed before the loss is
+// assembled (and before any all-reduce).  A strictly masked sweep skips unobserved entries, pads included --
+// except on the general path without a mask, where everything counts as observed.
+double ll_pad_of(const nbmf_ctx* c, int strict = 0) {
+  if (strict && c->data_kind != DATA_F64) return 0.0;
   const double n_pad = (double)c->mA * (double)c->nA - (double)c->m * (double)c->n;
-  return (c->data_kind == DATA_BIN) ? n_pad * log(1.0 + c->eps) : 0.0;
+  return n_pad * log(1.0 + c->eps);
 }
 
 // What travels after a sweep over image A (H-pass or Theta-only sweep), and where the global
@@ -638,7 +652,7 @@ double ll_pad_of(const nbmf_ctx* c) {
 //   axis 1 (columns)  [loglik, prior A, prior B]: the products stay local, the scalars do not
 int enqueue_exchange_after_sweep(nbmf_ctx* c, const PassArgs& a, bool with_products, int strict) {
   const int n_loss = c->chunksH * (a.Cb / WG_WAVES);   // one log-likelihood partial per workgroup
-  const double pad = strict ? 0.0 : ll_pad_of(c);
+  const double pad = ll_pad_of(c, strict);
   if (!is_sharded(c)) {
     c->ll_ptr = nullptr;
     return NBMF_OK;
@@ -789,7 +803,7 @@ int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false, i
   const bool sh = is_sharded(c) && c->ll_ptr;
   const double* ll_src = sh ? c->ll_ptr : c->lossbuf;
   const int n_ll = sh ? 1 : c->chunksH * (int)(c->nA / 16 / WG_WAVES);
-  const double pad = (sh || strict) ? 0.0 : ll_pad_of(c);
+  const double pad = sh ? 0.0 : ll_pad_of(c, strict);
   // axis 1: the prior sums were exchanged with the log-likelihood
   const bool prior_x = sh && c->shard_axis == 1;
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, ll_src, n_ll, pad,
@@ -1171,7 +1185,7 @@ void comm_release(nbmf_ctx* c, bool recount = false) {
   // the column split replaced the per-row observed counts by their global sums: back to this shard's own
   if (recount && is_sharded(c) && c->shard_axis == 1 && c->data_kind >= 0) {
     hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
-                       c->data_kind, (long long)(c->nA / 16), (long long)c->m, c->rowcnt);
+                       c->data_kind, (long long)(c->nA / 16), (long long)c->m, (long long)c->n, c->rowcnt);
     hipStreamSynchronize(c->stream);
   }
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
@@ -1335,7 +1349,8 @@ int nbmf_set_hyper(nbmf_ctx* c, double alpha, double beta, double eps, int proje
   if (!c) return fail(NBMF_ERR_ARG, "null context");
   if (projection != NBMF_PROJ_NORMALIZE && projection != NBMF_PROJ_DUCHI)
     return fail(NBMF_ERR_ARG, "unknown projection %d", projection);
-  if (!(eps > 0)) return fail(NBMF_ERR_ARG, "eps must be > 0");
+  if (!(eps >= 2.2250738585072014e-308 && eps <= 1.7976931348623157e308))
+    return fail(NBMF_ERR_ARG, "eps must be a positive normal number");
   c->alpha = alpha;
   c->beta = beta;
   c->eps = eps;
@@ -1356,25 +1371,21 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   // cheap host-side guess of the storage path from a sample (the device pack verifies it exactly);
   // NBMF_FORCE_F64=1 keeps binary data on the 8-byte path (measurement only)
   bool guess_bin = !(getenv("NBMF_FORCE_F64") && atoi(getenv("NBMF_FORCE_F64")) != 0);
-  if (guess_bin) {
+  bool guess_mask_bin = true;   // a float64 mask holding only 0 and 1 is a binary mask
+  {
     const int64_t rows = U < 8 ? U : 8;
-    for (int64_t u = 0; u < rows && guess_bin; ++u) {
+    for (int64_t u = 0; u < rows && (guess_bin || guess_mask_bin); ++u) {
       const int64_t uu = (U - 1) * u / (rows > 1 ? rows - 1 : 1);
       for (int64_t v = 0; v < V && v < 4096; ++v) {
         const double xv = x[uu * ldx + v];
-        if (xv != 0.0 && xv != 1.0) {
-          guess_bin = false;
-          break;
-        }
+        if (xv != 0.0 && xv != 1.0) guess_bin = false;
         if (mask_kind == NBMF_MASK_F64) {
           const double mk = ((const double*)mask)[uu * ldmask + v];
-          if (mk != 0.0 && mk != 1.0) {
-            guess_bin = false;
-            break;
-          }
+          if (mk != 0.0 && mk != 1.0) guess_mask_bin = false;
         }
       }
     }
+    if (!guess_mask_bin) guess_bin = false;
   }
 
   const size_t tiles = (size_t)(c->mA / 16) * (c->nA / 16);
@@ -1398,8 +1409,14 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
 
   int rc = NBMF_OK;
   unsigned long long st[4] = {0, 0, 0, 0};
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    const bool binary = (attempt == 0) ? guess_bin : false;
+  // Storage paths, cheapest first: byte codes (binary data, binary or no mask); doubles with a binary (or no)
+  // mask folded in as NaN; doubles plus weight tiles.  A path the sample suggested is dropped when the pack's
+  // exact counts say otherwise, and the next one is packed.
+  for (int kind : {DATA_BIN, DATA_F64, DATA_F64M}) {
+    if (kind == DATA_BIN && !guess_bin) continue;
+    if (kind == DATA_F64 && !guess_mask_bin) continue;
+    if (kind == DATA_F64M && mask_kind == NBMF_MASK_NONE) continue;
+    const bool binary = kind == DATA_BIN;
     for (void** p : {&c->dataA, &c->dataB, &c->maskA, &c->maskB}) {
       if (*p) hipFree(*p);
       *p = nullptr;
@@ -1409,10 +1426,8 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
     const size_t bytes = tiles * 256 * esz;
     HIPCHK(hipMalloc(&c->dataA, bytes));
     HIPCHK(hipMalloc(&c->dataB, bytes));
-    // pad tiles must read as "invalid": code 0 on the binary path, -1.0 on the f64 path
-    // (the pack kernel writes every tile of the padded mA x nA grid; out-of-range lanes get the
-    //  "invalid" marker: code 0 on the binary path, -1.0 on the f64 path)
-    if (!binary && mask_kind != NBMF_MASK_NONE) {
+    // (the pack kernel writes every tile of the padded mA x nA grid, pad entries included)
+    if (kind == DATA_F64M) {
       HIPCHK(hipMalloc(&c->maskA, bytes));
       HIPCHK(hipMalloc(&c->maskB, bytes));
     }
@@ -1441,6 +1456,7 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
       a.V = V;
       a.transposed = transposed;
       a.binary = binary ? 1 : 0;
+      a.fold_mask = kind == DATA_F64;
       a.dataA = c->dataA;
       a.dataB = c->dataB;
       a.maskA = c->maskA;
@@ -1459,9 +1475,10 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
       rc = fail(NBMF_ERR_RANGE, "X must be binary: %llu entries outside [0,1] or not finite", st[1]);
       break;
     }
-    const bool is_bin = (st[2] == 0 && st[3] == 0);
-    if (binary && !is_bin) continue;   // sample guessed wrong: repack as doubles
-    c->data_kind = binary ? DATA_BIN : (mask_kind != NBMF_MASK_NONE ? DATA_F64M : DATA_F64);
+    if (st[3] != 0) guess_mask_bin = false;   // exact now: weights that are not 0 or 1 need the weight tiles
+    if (kind == DATA_BIN && (st[2] != 0 || st[3] != 0)) continue;   // sample guessed wrong: repack as doubles
+    if (kind == DATA_F64 && st[3] != 0) continue;
+    c->data_kind = kind;
     break;
   }
   if (rc != NBMF_OK) return rc;
@@ -1470,7 +1487,7 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   c->n_obs = (mask_kind == NBMF_MASK_NONE) ? (double)c->m * (double)c->n : (double)st[0];
   c->n_obs_global = c->n_obs;
   hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
-                     c->data_kind, (long long)(c->nA / 16), (long long)c->m, c->rowcnt);
+                     c->data_kind, (long long)(c->nA / 16), (long long)c->m, (long long)c->n, c->rowcnt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   if (out_flags) *out_flags = (c->data_kind == DATA_BIN) ? NBMF_FLAG_BINARY_PATH : 0;
@@ -1506,7 +1523,7 @@ int nbmf_generate(nbmf_ctx* c, uint64_t seed, double density, double observed) {
   c->n_obs = (double)st[0];
   c->n_obs_global = c->n_obs;
   hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
-                     c->data_kind, (long long)(c->nA / 16), (long long)c->m, c->rowcnt);
+                     c->data_kind, (long long)(c->nA / 16), (long long)c->m, (long long)c->n, c->rowcnt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   return NBMF_OK;
@@ -1578,7 +1595,7 @@ int nbmf_upload_csr(nbmf_ctx* c, const int64_t* indptr, const int32_t* indices, 
   c->n_obs = masked ? (double)st[0] : (double)c->m * (double)c->n;
   c->n_obs_global = c->n_obs;
   hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
-                     c->data_kind, (long long)(c->nA / 16), (long long)c->m, c->rowcnt);
+                     c->data_kind, (long long)(c->nA / 16), (long long)c->m, (long long)c->n, c->rowcnt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   if (out_flags) *out_flags = NBMF_FLAG_BINARY_PATH;

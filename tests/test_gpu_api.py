@@ -214,3 +214,47 @@ def test_progress_reports_arrive_during_the_run():
         assert len(calls) >= n_iter // 10 and all(len(v) <= 11 for _, v in calls)
         assert [f for f, _ in calls] == list(np.cumsum([0] + [len(v) for _, v in calls[:-1]]))
         np.testing.assert_array_equal(np.concatenate([v for _, v in calls]), losses)
+
+
+def test_eps_range_and_log_of_a_negative_number():
+    """eps is a public argument (nbmf_mm_solver(eps=...)): far below the default the binary path's likelihood
+    product takes its per-entry form and still follows the oracle; a factor pair with Theta > 1 + eps gives the
+    reference's NaN loss (log of a negative number, _solver.py:150), also when an even number of entries are
+    negative; a denormal eps is refused."""
+    from nbmf_mm_amd import _hip, nbmf_mm_solver
+    from oracle import nbmf_oracle as orc
+    r = np.random.default_rng(4)
+    Y = (r.random((90, 140)) < 0.3).astype(np.float64)
+    for eps in (1e-80, 1e-200):
+        W, H, l, _, _ = nbmf_mm_solver(Y, 5, max_iter=12, tol=0, random_state=1, eps=eps)
+        Wr, Hr, lr, _, _ = orc.solve(Y, 5, max_iter=12, tol=0, random_state=1, eps=eps)
+        np.testing.assert_allclose(l, lr, rtol=1e-10, atol=0)
+        np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-9)
+    W0 = r.uniform(0.5, 0.9, (5, 90))                  # columns sum to ~3.5: Theta > 1 in many places
+    H0 = r.uniform(0.5, 0.9, (5, 140))
+    for Yc in (Y, r.random((90, 140))):                # binary path and general path
+        with _hip.Context(90, 140, 5) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            ctx.upload(Yc)
+            ctx.set_factors(W0, H0)
+            with np.errstate(all="ignore"):
+                want = orc.mm_loss(Yc, W0, H0, None, 1.2, 1.2)
+            assert np.isnan(want) and np.isnan(ctx.loss())
+    with _hip.Context(90, 140, 5) as ctx:
+        with pytest.raises(ValueError, match="normal"):
+            ctx.set_hyper(1.2, 1.2, eps=1e-310)
+
+
+def test_upload_is_refused_while_a_communicator_is_attached():
+    from nbmf_mm_amd import _hip
+    r = np.random.default_rng(5)
+    Y = (r.random((64, 80)) < 0.3).astype(np.float64)
+    with _hip.Context(64, 80, 4) as ctx:
+        ctx.set_hyper(1.2, 1.2)
+        ctx.upload(Y)
+        ctx.comm_init_host(lambda arr: None, 1, 0)
+        with pytest.raises(_hip.NBMFHipError, match="before attaching"):
+            ctx.upload(Y)
+        ctx.comm_detach()
+        ctx.upload(Y)

