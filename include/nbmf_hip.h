@@ -112,6 +112,12 @@ int nbmf_run(nbmf_ctx* ctx, int max_iter, double tol, double* losses, int* n_ite
 typedef void (*nbmf_progress_fn)(void* user, int first, int count, const double* losses);
 int nbmf_set_progress(nbmf_ctx* ctx, nbmf_progress_fn fn, void* user, int every);
 
+/* Diagnostics: how many nbmf_run calls of this context were served by the single-launch path for small problems
+ * (one persistent kernel runs the whole loop of _solver.py:143-175), and how many of those gave
+ * up at a grid barrier and were redone by the five-kernel path.  Environment: NBMF_PERSISTENT=0 switches the
+ * single-launch path off. */
+int nbmf_small_stats(nbmf_ctx* ctx, int* runs, int* aborted);
+
 /* n_steps repetitions of the simplex-factor update with the Beta factor frozen: the loop body of
  * NBMFMM.transform, _base.py:178-193 (always "normalize", eps as set by nbmf_set_hyper). */
 int nbmf_w_only_steps(nbmf_ctx* ctx, int n_steps);

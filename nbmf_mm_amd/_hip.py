@@ -33,7 +33,7 @@ SYMBOLS = [
     "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_loglik", "nbmf_loglik_strict", "nbmf_comm_unique_id", "nbmf_comm_init",
     "nbmf_comm_init_host", "nbmf_peer_export", "nbmf_comm_init_peer", "nbmf_comm_detach",
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
-    "nbmf_set_progress", "nbmf_device_synchronize",
+    "nbmf_set_progress", "nbmf_device_synchronize", "nbmf_small_stats",
 ]
 
 
@@ -121,6 +121,7 @@ def load():
     lib.nbmf_synchronize.argtypes = [c_void_p]
     lib.nbmf_set_progress.argtypes = [c_void_p, PROGRESS_FN, c_void_p, c_int]
     lib.nbmf_device_synchronize.argtypes = [c_int]
+    lib.nbmf_small_stats.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.nbmf_selftest_unary.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p]
     for name in SYMBOLS:
         if name != "nbmf_last_error":
@@ -325,6 +326,12 @@ class Context:
 
     def synchronize(self):
         _check(self._lib.nbmf_synchronize(self._h))
+
+    def small_stats(self):
+        """(runs served by the single-launch path for small problems, how many of those fell back)."""
+        r, a = c_int(0), c_int(0)
+        _check(self._lib.nbmf_small_stats(self._h, byref(r), byref(a)))
+        return r.value, a.value
 
     def set_progress(self, callback=None, every=10):
         """``callback(first, losses)`` is called from inside :meth:`run` with the losses of iterations

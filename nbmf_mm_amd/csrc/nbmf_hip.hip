@@ -234,6 +234,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 #include "nbmf_update_kernels.inc"
 #include "nbmf_pack_kernels.inc"
 #include "nbmf_peer_kernels.inc"
+#include "nbmf_small_kernel.inc"
 
 }  // namespace
 
@@ -306,6 +307,16 @@ struct nbmf_ctx {
   long long offHX = 0, offPR = 0, offSC = 0, x_doubles = 0;
   long long sl_c0 = 0, sl_wp = 0;   // axis 0: the column slice of H this rank updates
   double *Pbuf_own = nullptr, *sbuf_own = nullptr, *Qbuf_own = nullptr;   // the private buffers while the arena stands in
+  // the whole-fit-in-one-launch path for small problems (nbmf_small_kernel.inc): second parity of the factor
+  // images, hand-off words, a snapshot of the factors for the fall-back
+  struct SmallWs {
+    double *Wn = nullptr, *WT = nullptr, *WG = nullptr, *Hn = nullptr, *HT = nullptr, *HG = nullptr;
+    double *snapW = nullptr, *snapH = nullptr, *ll_part = nullptr, *prior_part = nullptr;
+    unsigned long long* sync = nullptr;
+    int* result = nullptr;
+    bool ready = false, disabled = false;
+    int runs = 0, aborted = 0;   // statistics (nbmf_small_stats)
+  } small;
   // progress reports out of nbmf_run (nbmf_set_progress)
   nbmf_progress_fn progress = nullptr;
   void* progress_user = nullptr;
@@ -1133,6 +1144,161 @@ int enqueue_w_step(nbmf_ctx* c, int projection) {
   return enqueue_w_update(c, q, chunks, n_div, projection);
 }
 
+// ---- small problems: the fit in one persistent launch (nbmf_small_kernel.inc) ------------------------------
+// natural padded [KP][lenA] -> T and G images (restoring the factors after an abandoned persistent run)
+__global__ void expand_factor_kernel(const double* __restrict__ Fn, double* __restrict__ FT, double* __restrict__ FG, int KP,
+                                     int KS, long long lenA) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)KP * lenA) return;
+  const long long k = idx / lenA, x = idx % lenA;
+  FT[t_index(k, x, KS, lenA)] = Fn[idx];
+  FG[g_index(k, x, KS, lenA)] = Fn[idx];
+}
+
+template <int KB>
+const void* small_ptr(int data_kind) {
+  switch (data_kind) {
+    case DATA_BIN: return (const void*)small_fit_kernel<KB, DATA_BIN>;
+    case DATA_F64: return (const void*)small_fit_kernel<KB, DATA_F64>;
+    case DATA_F64M: return (const void*)small_fit_kernel<KB, DATA_F64M>;
+  }
+  return nullptr;
+}
+
+// Is this run one for the persistent kernel?  One GPU, at most 32 components (the 16-wave workgroups leave 128
+// registers per lane), no per-launch instrumentation asked for, and few enough tiles that a wave sweeps at most
+// SM_TPW of them per phase -- beyond that (NBMF_SMALL_TILES, default 4096 tiles) the five-kernel path with its
+// LDS-staged panels is the faster one.
+bool small_eligible(const nbmf_ctx* c, int cus) {
+  if (c->small.disabled || is_sharded(c) || c->KS != 1 || c->KB > 2 || c->timing || (c->progress && c->progress_every > 0)) return false;
+  if (const char* e = getenv("NBMF_PERSISTENT"))
+    if (atoi(e) == 0) return false;
+  const long long Rbe = (c->m + 15) / 16, Cbe = (c->n + 15) / 16;
+  long long max_tiles = 4096;
+  if (const char* e = getenv("NBMF_SMALL_TILES")) max_tiles = atoll(e);
+  const long long cap = sm_waves(c->KB) * SM_TPW;
+  return Rbe <= cap && Cbe <= cap && std::max(Rbe, Cbe) <= cus && Rbe * Cbe <= max_tiles;
+}
+
+int small_prepare(nbmf_ctx* c) {
+  if (c->small.ready) return NBMF_OK;
+  const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
+  for (double** p : {&c->small.Wn, &c->small.WT, &c->small.WG, &c->small.snapW}) {
+    HIPCHK(hipMalloc(p, fw));
+    HIPCHK(hipMemsetAsync(*p, 0, fw, c->stream));   // pad strips are never written: they must read as zero
+  }
+  for (double** p : {&c->small.Hn, &c->small.HT, &c->small.HG, &c->small.snapH}) {
+    HIPCHK(hipMalloc(p, fh));
+    HIPCHK(hipMemsetAsync(*p, 0, fh, c->stream));
+  }
+  const size_t g_max = 16 * SM_TPW;
+  HIPCHK(hipMalloc(&c->small.sync, sizeof(unsigned long long) * (g_max + 8)));
+  HIPCHK(hipMalloc(&c->small.ll_part, sizeof(double) * g_max));
+  HIPCHK(hipMalloc(&c->small.prior_part, sizeof(double) * 4 * g_max));
+  HIPCHK(hipMalloc(&c->small.result, sizeof(int) * 4));
+  c->small.ready = true;
+  return NBMF_OK;
+}
+
+// Returns NBMF_OK with *handled = true when the run is complete (losses, n_iter filled, factors in the context's
+// buffers); *handled = false means "use the five-kernel path" (factors restored to their state at entry).
+int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter, bool* handled) {
+  *handled = false;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, c->device));
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (!small_eligible(c, cus)) return NBMF_OK;
+  if (int rc = small_prepare(c)) return rc;
+  auto& w = c->small;
+  const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
+  SmallArgs a{};
+  a.dataA = c->dataA;
+  a.maskA = c->maskA;
+  a.dataB = c->dataB;
+  a.maskB = c->maskB;
+  a.Wn[0] = w.Wn; a.WT[0] = w.WT; a.WG[0] = w.WG; a.Hn[0] = w.Hn; a.HT[0] = w.HT; a.HG[0] = w.HG;
+  a.Wn[1] = c->Wn; a.WT[1] = c->WT; a.WG[1] = c->WG; a.Hn[1] = c->Hn; a.HT[1] = c->HT; a.HG[1] = c->HG;
+  a.rowcnt = c->rowcnt;
+  a.sync = w.sync;
+  a.ll_part = w.ll_part;
+  a.prior_part = w.prior_part;
+  a.losses = c->losses_d;
+  a.result = w.result;
+  a.m = c->m; a.n = c->n; a.mA = c->mA; a.nA = c->nA;
+  a.K = c->k;
+  a.RbA = (int)(c->mA / 16);
+  a.CbA = (int)(c->nA / 16);
+  a.Rbe = (int)((c->m + 15) / 16);
+  a.Cbe = (int)((c->n + 15) / 16);
+  a.G = std::max(a.Rbe, a.Cbe);
+  a.max_iter = max_iter;
+  a.projection = c->projection;
+  a.tiny_eps = c->eps < 1e-70;
+  a.tol = tol;
+  a.eps = c->eps;
+  a.am1 = c->alpha - 1.0;
+  a.bm1 = c->beta - 1.0;
+  a.n_obs = c->n_obs_global;
+  a.n_div = (double)c->n;
+  a.ll_pad = (256.0 * a.Rbe * a.Cbe - (double)c->m * (double)c->n) * log(1.0 + c->eps);
+  double ms = 2000.0;
+  if (const char* e = getenv("NBMF_SMALL_TIMEOUT_MS")) ms = std::max(1.0, atof(e));
+  a.timeout = (unsigned long long)(ms * 1e5);
+  const void* f = c->KB == 1 ? small_ptr<1>(c->data_kind) : small_ptr<2>(c->data_kind);
+  if (!f) return NBMF_OK;
+  const int NW = sm_waves(c->KB);
+  const size_t lds_bytes = sizeof(double) * ((size_t)NW * 2 * c->KB * 4 * 64 + NW * 16 + 64 + 2 * c->KP * 16) + LOG_TABLE_BYTES;
+  HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  // snapshot for the fall-back, hand-off words cleared
+  HIPCHK(hipMemcpyAsync(w.snapW, c->Wn, fw, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(w.snapH, c->Hn, fh, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(w.sync, 0, sizeof(unsigned long long) * (a.G + 1), c->stream));
+  HIPCHK(hipMemsetAsync(w.result, 0, sizeof(int) * 4, c->stream));
+  if (getenv("NBMF_SMALL_FORCE_ABORT")) {   // tests: raise the abort word up front, so that the fall-back runs
+    const unsigned long long one = 1;
+    HIPCHK(hipMemcpyAsync(w.sync + a.G, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
+  }
+  void* params[] = {&a};
+  HIPCHK(hipLaunchKernel(f, dim3(a.G), dim3(64 * NW), params, lds_bytes, c->stream));
+  int res[4] = {0, 0, 0, 0};
+  unsigned long long abort_word = 0;
+  HIPCHK(hipMemcpyAsync(res, w.result, sizeof res, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&abort_word, w.sync + a.G, sizeof abort_word, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  ++w.runs;
+  if (res[2] != 0 || abort_word != 0 || res[0] < 1 || res[0] > max_iter) {
+    // a barrier was abandoned (workgroups not co-resident for too long): back to the state at entry, and this
+    // context keeps to the five-kernel path from now on
+    ++w.aborted;
+    w.disabled = true;
+    HIPCHK(hipMemcpyAsync(c->Wn, w.snapW, fw, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->Hn, w.snapH, fh, hipMemcpyDeviceToDevice, c->stream));
+    const long long tw = (long long)c->KP * c->mA, th = (long long)c->KP * c->nA;
+    hipLaunchKernelGGL(expand_factor_kernel, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->Wn,
+                       c->WT, c->WG, c->KP, c->KP, (long long)c->mA);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(expand_factor_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->Hn,
+                       c->HT, c->HG, c->KP, c->KP, (long long)c->nA);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (getenv("NBMF_DEBUG")) fprintf(stderr, "[nbmf] persistent fit abandoned (status %d, abort word %llu): five-kernel path\n", res[2], abort_word);
+    return NBMF_OK;
+  }
+  if (res[1] == 0) {   // the final factors sit in the second set of images
+    HIPCHK(hipMemcpyAsync(c->Wn, w.Wn, fw, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->WT, w.WT, fw, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->WG, w.WG, fw, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->Hn, w.Hn, fh, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->HT, w.HT, fh, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->HG, w.HG, fh, hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIPCHK(hipMemcpyAsync(losses, c->losses_d, sizeof(double) * (size_t)res[0], hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *n_iter = res[0];
+  *handled = true;
+  return NBMF_OK;
+}
+
 int ensure_losses(nbmf_ctx* c, int cap) {
   if (cap <= c->losses_cap) return NBMF_OK;
   if (c->losses_d) HIPCHK(hipFree(c->losses_d));
@@ -1330,7 +1496,9 @@ int nbmf_destroy(nbmf_ctx* c) {
   arena_release((ArenaSlot*)c->arena_slot.p);   // back to the pool, never to the allocator (see ArenaSlot)
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
                   c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
-                  c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta};
+                  c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta, c->small.Wn, c->small.WT, c->small.WG, c->small.Hn,
+                  c->small.HT, c->small.HG, c->small.snapW, c->small.snapH, c->small.ll_part, c->small.prior_part,
+                  c->small.sync, c->small.result};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (hipEvent_t e : c->ev) hipEventDestroy(e);
@@ -1668,6 +1836,11 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   if (int rc = ensure_losses(c, max_iter)) return rc;
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->scal, 0, sizeof(double) * 8, c->stream));
+  {
+    bool handled = false;   // small problems: the whole run in one persistent launch
+    if (int rc = run_small(c, max_iter, tol, losses, n_iter, &handled)) return rc;
+    if (handled) return NBMF_OK;
+  }
 
   // Timeline (N3 of SURVEY Appendix A): the H-pass of iteration t also yields the log-likelihood of
   // the factors after iteration t-1, so loss(t-1) and its stop test are settled before H-update(t).
@@ -2070,6 +2243,13 @@ int nbmf_set_progress(nbmf_ctx* c, nbmf_progress_fn fn, void* user, int every) {
   c->progress = fn;
   c->progress_user = user;
   c->progress_every = fn ? every : 0;
+  return NBMF_OK;
+}
+
+int nbmf_small_stats(nbmf_ctx* c, int* runs, int* aborted) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (runs) *runs = c->small.runs;
+  if (aborted) *aborted = c->small.aborted;
   return NBMF_OK;
 }
 

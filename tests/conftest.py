@@ -45,3 +45,11 @@ def midsize_XM():
     X = (g.random((512, 512)) < 0.25).astype(np.float64)
     M = (g.random((512, 512)) < 0.9).astype(np.float64)
     return X, M
+
+
+@pytest.fixture(params=["single-launch", "five-kernels"])
+def both_small_paths(request, monkeypatch):
+    """Small problems take the single-launch path (one persistent kernel runs the whole loop) unless it is
+    switched off; tests that use this fixture run once each way, so both engines face the same oracle."""
+    monkeypatch.setenv("NBMF_PERSISTENT", "1" if request.param == "single-launch" else "0")
+    return request.param

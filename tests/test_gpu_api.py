@@ -258,3 +258,53 @@ def test_upload_is_refused_while_a_communicator_is_attached():
             ctx.upload(Y)
         ctx.comm_detach()
         ctx.upload(Y)
+
+
+def test_single_launch_path_serves_small_problems_and_falls_back_cleanly(monkeypatch):
+    """Small fits run inside one persistent kernel (nbmf_small_kernel.inc); the five-kernel path gives the same
+    curve to rounding and takes over, from the factors as they were at entry, when a grid barrier is abandoned
+    (provoked here by raising the abort word before the launch)."""
+    from nbmf_mm_amd import _hip
+    from oracle import nbmf_oracle as orc
+    r = np.random.default_rng(8)
+    stopped_early = False
+    for (m, n, k, real) in [(100, 500, 6, False), (253, 902, 8, False), (1226, 285, 16, False), (77, 130, 20, True), (300, 200, 32, False)]:
+        Y = r.random((m, n)) if real else (r.random((m, n)) < 0.3).astype(np.float64)
+        mask = r.random((m, n)) < 0.85
+        W0 = r.uniform(0.1, 0.9, (k, m))
+        W0 /= W0.sum(axis=0, keepdims=True)
+        H0 = r.uniform(0.1, 0.9, (k, n))
+        out = {}
+        for mode in ("single", "five", "abort"):
+            monkeypatch.setenv("NBMF_PERSISTENT", "0" if mode == "five" else "1")
+            if mode == "abort":
+                monkeypatch.setenv("NBMF_SMALL_FORCE_ABORT", "1")
+            else:
+                monkeypatch.delenv("NBMF_SMALL_FORCE_ABORT", raising=False)
+            with _hip.Context(m, n, k) as ctx:
+                ctx.set_hyper(1.1, 1.3, 1e-8, _hip.PROJ_DUCHI if k == 8 else _hip.PROJ_NORMALIZE)
+                ctx.upload(Y, mask=mask)
+                ctx.set_factors(W0, H0)
+                l1, n1 = ctx.run(25, 0.0)
+                l2, n2 = ctx.run(400, 1e-4)                  # continues from the state the first run left
+                out[mode] = (np.concatenate([l1, l2]), n2) + ctx.get_factors() + (ctx.small_stats(),)
+        assert out["single"][4] == (2, 0) and out["five"][4] == (0, 0) and out["abort"][4] == (1, 1)
+        assert 2 < out["single"][1] <= 400 and out["single"][1] == out["five"][1] == out["abort"][1]
+        stopped_early = stopped_early or out["single"][1] < 400
+        np.testing.assert_allclose(out["single"][0], out["five"][0], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(out["single"][2], out["five"][2], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(out["single"][3], out["five"][3], rtol=0, atol=1e-12)
+        for j in (0, 2, 3):
+            np.testing.assert_array_equal(out["abort"][j], out["five"][j])     # the fall-back IS the five-kernel path
+    assert stopped_early
+    # and against the oracle, both stop-rule bookkeeping and the factors of the stop iteration
+    Yb = (r.random((120, 90)) < 0.3).astype(np.float64)
+    monkeypatch.setenv("NBMF_PERSISTENT", "1")
+    monkeypatch.delenv("NBMF_SMALL_FORCE_ABORT", raising=False)
+    from nbmf_mm_amd import nbmf_mm_solver
+    W, H, l, _, nit = nbmf_mm_solver(Yb, 5, max_iter=500, tol=1e-5, random_state=3)
+    Wr, Hr, lr, _, nr = orc.solve(Yb, 5, max_iter=500, tol=1e-5, random_state=3)
+    assert nit == nr and 2 < nit < 500
+    np.testing.assert_allclose(l, lr, rtol=1e-10, atol=0)
+    np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-9)

@@ -76,7 +76,7 @@ def test_log_accuracy(hip):
         np.testing.assert_array_equal(hip.selftest_unary(1, sp), np.log(sp))
 
 
-def test_one_step_golden_vectors(hip, golden):
+def test_one_step_golden_vectors(hip, golden, both_small_paths):
     g = golden("one_step")
     for i in range(int(g["n_cases"])):
         p = f"c{i}_"
@@ -91,7 +91,7 @@ def test_one_step_golden_vectors(hip, golden):
         assert binpath == (i < 18)          # the last vector is real-valued with a weight mask
 
 
-def test_config1_curve(hip, golden):
+def test_config1_curve(hip, golden, both_small_paths):
     from nbmf_mm_amd import NBMF
     g = golden("config1")
     mdl = NBMF(n_components=6, orientation="beta-dir", alpha=1.2, beta=1.2, random_state=0,
@@ -106,7 +106,7 @@ def test_config1_curve(hip, golden):
     assert abs(mdl.loss_ - float(g["default_loss"])) <= 1e-10 * float(g["default_loss"])
 
 
-def test_dir_beta(hip, golden):
+def test_dir_beta(hip, golden, both_small_paths):
     from nbmf_mm_amd import NBMF
     g = golden("dir_beta")
     X = config1_X()
@@ -120,7 +120,7 @@ def test_dir_beta(hip, golden):
     np.testing.assert_array_equal(mdl.loss_curve_, mdlT.loss_curve_)
 
 
-def test_masked_float_and_bool(hip, golden):
+def test_masked_float_and_bool(hip, golden, both_small_paths):
     from nbmf_mm_amd import NBMF
     g = golden("masked")
     X, mask = config1_X(), config1_mask()
@@ -135,7 +135,7 @@ def test_masked_float_and_bool(hip, golden):
     assert all(l[i] <= l[i - 1] + 1e-12 for i in range(1, len(l)))
 
 
-def test_real_valued(hip, golden):
+def test_real_valued(hip, golden, both_small_paths):
     from nbmf_mm_amd import NBMF
     g = golden("real_valued")
     Xr = np.random.default_rng(3).random((50, 30))
@@ -145,7 +145,7 @@ def test_real_valued(hip, golden):
     np.testing.assert_allclose(mdl.components_, g["H"], rtol=0, atol=FACTOR_ATOL)
 
 
-def test_custom_init_both_orientations(hip, golden):
+def test_custom_init_both_orientations(hip, golden, both_small_paths):
     from nbmf_mm_amd import NBMF
     g = golden("custom_init")
     mdl = NBMF(n_components=4, random_state=123, max_iter=50, tol=1e-8, W_init=g["W0"], H_init=g["H0"]).fit(g["Y"])
@@ -161,7 +161,7 @@ def test_custom_init_both_orientations(hip, golden):
         NBMF(n_components=4, orientation="dir-beta", max_iter=2, W_init=g["Wd0"]).fit(g["Y"])
 
 
-def test_stop_rule_counts(hip, golden):
+def test_stop_rule_counts(hip, golden, both_small_paths):
     from nbmf_mm_amd import NBMF
     g = golden("stop_rule")
     hi = NBMF(n_components=5, tol=0.1, max_iter=1000, random_state=42).fit(g["X"])
@@ -251,7 +251,7 @@ def test_transform_score_perplexity(hip, golden):
     assert (W_pin @ Hbig).max() > 1.0 and abs(dev - want) <= 1e-12 * abs(want)
 
 
-def test_midsize_curves(hip, golden):
+def test_midsize_curves(hip, golden, both_small_paths):
     """512x512 (K=32, 500 its), masked (300 its), dir-beta masked K=64, real-valued weighted K=16."""
     from nbmf_mm_amd import nbmf_mm_solver
     g = golden("midsize")
@@ -275,7 +275,7 @@ def test_midsize_curves(hip, golden):
 @pytest.mark.parametrize("m,n,k", [(1, 1, 1), (17, 5, 3), (130, 257, 17), (200, 129, 33), (64, 300, 100),
                                    (129, 128, 128), (16, 16, 16),
                                    (150, 200, 129), (257, 190, 256), (40, 333, 300)])   # > 128: slices sharing a stored Theta
-def test_ragged_shapes_vs_oracle(hip, m, n, k):
+def test_ragged_shapes_vs_oracle(hip, m, n, k, both_small_paths):
     """Edge shapes: not multiples of the 16x16 tile or the 128 padding; every K template."""
     r = np.random.default_rng(m * 1000 + n)
     Y = (r.random((m, n)) < 0.4).astype(np.float64)
@@ -346,7 +346,7 @@ def test_more_than_128_components(hip):
     np.testing.assert_allclose(d.W_.sum(axis=1), 1.0, atol=1e-12)
 
 
-def test_bitwise_run_to_run(hip):
+def test_bitwise_run_to_run(hip, both_small_paths):
     from nbmf_mm_amd import NBMF
     X, M = midsize_XM()
     a = NBMF(n_components=32, random_state=7, max_iter=40, tol=0).fit(X[:300, :411], mask=M[:300, :411])
@@ -356,7 +356,7 @@ def test_bitwise_run_to_run(hip):
     np.testing.assert_array_equal(a.loss_curve_, b.loss_curve_)
 
 
-def test_duchi_extension_properties(hip):
+def test_duchi_extension_properties(hip, both_small_paths):
     """projection='duchi' (README.md:27-35; parity unpinned): simplex exact, tracks the CPU
     restatement of the same extension, near-identical to 'normalize' when unmasked."""
     from nbmf_mm_amd import NBMF
@@ -371,7 +371,7 @@ def test_duchi_extension_properties(hip):
     np.testing.assert_allclose(du.loss_curve_, nrm.loss_curve_, rtol=1e-6)
 
 
-def test_loss_entry_point_matches_oracle(hip):
+def test_loss_entry_point_matches_oracle(hip, both_small_paths):
     r = np.random.default_rng(5)
     Y = (r.random((90, 70)) < 0.3).astype(np.float64)
     W = r.uniform(0.1, 0.9, (7, 90)); W /= W.sum(axis=0, keepdims=True)
@@ -446,7 +446,7 @@ def _dense_any(a):
     return a.toarray() if hasattr(a, "toarray") else a
 
 
-def test_edge_cases_vs_oracle(hip):
+def test_edge_cases_vs_oracle(hip, both_small_paths):
     """Degenerate and boundary inputs the domain offers: constant matrices, K larger than the matrix,
     priors below 1 (negative a, b: the clip is what keeps H in range), rows/columns with nothing
     observed, a mask observing almost nothing, single row / single column."""
@@ -492,7 +492,7 @@ def test_input_types_accepted_like_the_reference(hip):
     np.testing.assert_array_equal(a.W_, b.W_)
 
 
-def test_last_loss_sweep_is_bitwise_the_fused_one(hip):
+def test_last_loss_sweep_is_bitwise_the_fused_one(hip, both_small_paths):
     """The loss of the final iteration comes from the Theta-only sweep, every earlier one from the fused
     H-pass of the following iteration; both must give the same bits (so a run of k iterations is a prefix
     of a run of k+1), on the binary and on the general storage path, K = 64 and K = 128."""
@@ -534,6 +534,7 @@ def test_graph_replay_matches_eager(hip, monkeypatch):
     from nbmf_mm_amd import nbmf_mm_solver
     X, M = midsize_XM()
     X, M = X[:200, :333], M[:200, :333]
+    monkeypatch.setenv("NBMF_PERSISTENT", "0")       # (a problem of this size would otherwise never reach the launches)
     monkeypatch.delenv("NBMF_USE_GRAPH", raising=False)
     W0, H0, l0, _, n0 = nbmf_mm_solver(X, 12, max_iter=300, tol=1e-4, random_state=3, mask=M)
     Wf, Hf, lf, _, nf = nbmf_mm_solver(X, 12, max_iter=40, tol=0, random_state=3, mask=M)
@@ -583,7 +584,7 @@ def test_storage_path_is_decided_by_the_whole_matrix(hip):
     assert abs(a - orc.mm_loss(Y, W, H, mask, 1.2, 1.2)) <= 1e-12
 
 
-def test_fuzz_against_oracle(hip):
+def test_fuzz_against_oracle(hip, both_small_paths):
     """Seeded random configurations: shapes straddling the 16 / 128 padding units, every K template,
     both orientations, mask kinds (none / bool / float 0-1 / weights), real-valued data, priors on both
     sides of 1, both projections (the Duchi extension against the oracle's restatement of it)."""
@@ -635,7 +636,7 @@ def test_on_device_synthetic_data_matches_its_numpy_twin(hip):
         np.testing.assert_array_equal(a, b)
 
 
-def test_seeded_sweep_of_configurations_vs_oracle(hip):
+def test_seeded_sweep_of_configurations_vs_oracle(hip, both_small_paths):
     """Forty pseudo-random small problems (shape, K from 1 to 200, density, mask kind, orientation, priors,
     real-valued or binary data, projection) against the oracle: the parity net under the hand-picked cases."""
     from nbmf_mm_amd import nbmf_mm_solver

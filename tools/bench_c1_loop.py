@@ -1,16 +1,29 @@
 #!/usr/bin/env python3
-"""BASELINE configs[0] (100 x 500, K = 6) through the ctypes layer: 5000 iterations, for kernel-level profiles of
-the latency-bound regime."""
+"""Small problems through the ctypes layer, iterations per second in the loop: BASELINE configs[0] (100 x 500, K = 6)
+and the shapes of the reference's own datasets (examples/reproduce_magron2022.py:49-73), by the single-launch
+path (nbmf_small_kernel.inc) and by the five-kernel path (NBMF_PERSISTENT=0)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from nbmf_mm_amd import _hip, _dist
-X = (np.random.default_rng(0).random((100, 500)) < 0.25).astype(np.float64)
-W, H = _dist.global_init(100, 500, 6, random_state=0)
-with _hip.Context(100, 500, 6) as ctx:
-    ctx.set_hyper(1.2, 1.2)
-    ctx.upload(X)
-    ctx.set_factors(W, H)
-    ctx.run(50, 0.0)
-    t0 = time.perf_counter(); losses, n = ctx.run(5000, 0.0); dt = time.perf_counter() - t0
-    print(f"{n / dt:.0f} it/s, {1e6 * dt / n:.1f} us per iteration, loss {losses[199 - 50]:.15f}")
+CASES = [("configs[0] 100x500 K=6", 100, 500, 6), ("animals 50x85 K=4", 50, 85, 4), ("paleo 253x902 K=8", 253, 902, 8),
+         ("lastfm 1226x285 K=8", 1226, 285, 8), ("lastfm 1226x285 K=16", 1226, 285, 16), ("1024x1024 K=16", 1024, 1024, 16),
+         ("1024x1024 K=32", 1024, 1024, 32), ("2000x2000 K=16", 2000, 2000, 16)]
+its = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+for name, m, n, k in CASES:
+    X = (np.random.default_rng(0).random((m, n)) < 0.25).astype(np.float64)
+    W, H = _dist.global_init(m, n, k, random_state=0)
+    row = []
+    for mode in ("1", "0"):
+        os.environ["NBMF_PERSISTENT"] = mode
+        with _hip.Context(m, n, k) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            ctx.upload(X)
+            ctx.set_factors(W, H)
+            ctx.run(50, 0.0)
+            ctx.set_factors(W, H)
+            t0 = time.perf_counter(); losses, nit = ctx.run(its, 0.0); dt = time.perf_counter() - t0
+            row.append((nit / dt, 1e6 * dt / nit, losses[min(199, nit - 1)], ctx.small_stats()))
+    (a, ua, la, sa), (b, ub, lb, sb) = row
+    print(f"{name:24s} single launch {a:9.0f} it/s ({ua:6.2f} us/it, runs/aborted {sa})   five kernels {b:9.0f} it/s ({ub:6.2f} us/it)   "
+          f"loss[199] {la:.15f} vs {lb:.15f}", flush=True)
