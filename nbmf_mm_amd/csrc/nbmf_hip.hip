@@ -166,7 +166,7 @@ template <bool GUARD>
 __device__ __forceinline__ double log_tab(double x, const double2* tab) {
   if (GUARD && __builtin_expect(!__builtin_amdgcn_class(x, 0x100), 0)) return log(x);   // not a positive normal number
   const uint32_t hi = (uint32_t)__double2hiint(x);
-  const double m = mk_double((uint32_t)__double2loint(x), (hi & 0x000FFFFFu) | 0x3FE00000u);
+  const double m = __builtin_amdgcn_frexp_mant(x);   // in [0.5, 1); a NaN stays a NaN and so reaches the result
   const double2 e = tab[(hi >> 12) & 0xFFu];
   const double r = __builtin_fma(m, e.x, -1.0);
   double p = __builtin_fma(r, 0.2, -0.25);
@@ -1193,8 +1193,8 @@ int small_prepare(nbmf_ctx* c) {
   }
   const size_t g_max = 16 * SM_TPW;
   HIPCHK(hipMalloc(&c->small.sync, sizeof(unsigned long long) * (g_max + 8)));
-  HIPCHK(hipMalloc(&c->small.ll_part, sizeof(double) * g_max));
-  HIPCHK(hipMalloc(&c->small.prior_part, sizeof(double) * 4 * g_max));
+  HIPCHK(hipMalloc(&c->small.ll_part, sizeof(double) * g_max));                 // [strip]
+  HIPCHK(hipMalloc(&c->small.prior_part, sizeof(double) * 2 * g_max * 8 * 2));  // [parity][strip][updating wave][2]
   HIPCHK(hipMalloc(&c->small.result, sizeof(int) * 4));
   c->small.ready = true;
   return NBMF_OK;
@@ -1258,8 +1258,43 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
     const unsigned long long one = 1;
     HIPCHK(hipMemcpyAsync(w.sync + a.G, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
   }
+  unsigned long long* dbg = nullptr;
+  if (getenv("NBMF_SMALL_DEBUG")) {
+    HIPCHK(hipMalloc(&dbg, sizeof(unsigned long long) * 64 * 16));
+    HIPCHK(hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 64 * 16, c->stream));
+    a.dbg = dbg;
+  }
   void* params[] = {&a};
   HIPCHK(hipLaunchKernel(f, dim3(a.G), dim3(64 * NW), params, lds_bytes, c->stream));
+  if (dbg) {   // per-phase wall clock of workgroup 0 (10 ns ticks): tiles | update | barrier | tiles | update+loss | barrier
+    unsigned long long h[64 * 16];
+    HIPCHK(hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(dbg);
+    double acc[8] = {0}, fine[7] = {0};
+    int cnt = 0;
+    for (int t = 8; t < 63 && t + 1 < max_iter; ++t) {
+      if (!h[t * 16 + 7] || !h[(t + 1) * 16]) continue;
+      for (int p = 0; p < 7; ++p) acc[p] += (double)(h[t * 16 + p + 1] - h[t * 16 + p]) * 0.01;
+      acc[7] += (double)(h[(t + 1) * 16] - h[t * 16 + 7]) * 0.01;
+      fine[0] += (double)(h[t * 16 + 8] - h[t * 16 + 3]) * 0.01;    // barrier exit -> operand loads issued
+      fine[1] += (double)(h[t * 16 + 9] - h[t * 16 + 8]) * 0.01;    // -> operands landed
+      fine[2] += (double)(h[t * 16 + 10] - h[t * 16 + 9]) * 0.01;   // -> first tile's arithmetic done
+      fine[3] += (double)(h[t * 16 + 11] - h[t * 16 + 10]) * 0.01;  // -> second tile's
+      fine[4] += (double)(h[t * 16 + 12] - h[t * 16 + 1]) * 0.01;   // H: tiles done -> all waves' partials in LDS
+      fine[5] += (double)(h[t * 16 + 13] - h[t * 16 + 12]) * 0.01;  // -> update computed, stores issued
+      fine[6] += (double)(h[t * 16 + 2] - h[t * 16 + 13]) * 0.01;   // -> prior sums published
+      ++cnt;
+    }
+    if (cnt)
+      fprintf(stderr, "[nbmf]   W tiles of wave 0 in detail: issue %.2f | operands land %.2f | tile A %.2f | tile B %.2f;  H reduce+update: "
+                      "wait for all waves %.2f | update %.2f | prior sums %.2f\n", fine[0] / cnt, fine[1] / cnt, fine[2] / cnt, fine[3] / cnt,
+              fine[4] / cnt, fine[5] / cnt, fine[6] / cnt);
+    if (cnt)
+      fprintf(stderr, "[nbmf] persistent fit, workgroup 0, us per iteration part (mean of %d): H tiles %.2f | H reduce+update %.2f | barrier %.2f | "
+                      "W tiles %.2f | W reduce+update %.2f | loss %.2f | barrier %.2f | loop %.2f\n", cnt, acc[0] / cnt, acc[1] / cnt,
+              acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt, acc[7] / cnt);
+  }
   int res[4] = {0, 0, 0, 0};
   unsigned long long abort_word = 0;
   HIPCHK(hipMemcpyAsync(res, w.result, sizeof res, hipMemcpyDeviceToHost, c->stream));

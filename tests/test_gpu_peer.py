@@ -11,6 +11,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _single_process_reference_on_the_five_kernel_path(monkeypatch):
+    """The sharded runs below are compared, some of them bit for bit, with single-process runs of the same small
+    problems; those would take the single-launch path (another order of additions), so it is switched off here --
+    tests/test_gpu_parity.py and tests/test_gpu_api.py hold the two engines against each other and the oracle."""
+    monkeypatch.setenv("NBMF_PERSISTENT", "0")
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
