@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: --M rows PER GPU (e.g. --M 32768 --gpus 8 = BASELINE configs[3], 262144 x 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "rccl2", "host"],
+    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "peer2", "rccl", "rccl2", "host"],
                     help="exchange transport for --gpus > 1: peer = the library's own kernels over xGMI (HIP IPC), rccl = RCCL "
                          "all-reduce, host = gloo through pinned memory (tests only); rccl2 = RCCL in two "
                          "overlapped panels; auto = peer and rccl are each timed over five iterations before the run and the faster "
@@ -237,7 +237,7 @@ def main():
     if world > 1:
         if args.transport == "auto":
             # time a few iterations over each transport that attaches and keep the faster one (setup, untimed)
-            transport, trials = _dist.attach_fastest(ctx, group, reset)
+            transport, trials = _dist.attach_fastest(ctx, group, reset, candidates=("peer", "peer2", "rccl"))
         else:
             transport = _dist.attach_comm(ctx, group, args.transport)
     elif args.force_comm:
@@ -314,8 +314,8 @@ def main():
                        "devices": devices,
                        "transport_trials_s_per_5_iterations": trials,
                        "sharding": (f"rows/{world} ({transport}: " + ("reduce-scatter of 2*K*N+1 doubles fused with the H-update, K*N back"
-                                                             if transport == "peer" else "all-reduce of 2*K*N+1 doubles"
-                                                             + (" in two overlapped panels" if transport == "rccl2" else ""))
+                                                             if transport.startswith("peer") else "all-reduce of 2*K*N+1 doubles"
+                                                             + (" in two overlapped panels" if transport.endswith("2") else ""))
                                     + " per iteration)") if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -51,8 +51,9 @@ def attach_comm(ctx, group, transport="auto", shard_axis=0):
 
     transport "peer": the library's own exchange kernels over xGMI (HIP-IPC mapped arenas; the H-update is
                       fused into a reduce-scatter).  One process per rank.
-    transport "rccl": RCCL all-reduce on the library's stream ("rccl2": in two column panels, the second
-                      overlapped with compute; rows split only).
+    transport "rccl": RCCL all-reduce on the library's stream.
+    "peer2" / "rccl2": the same in two column panels, the second one's exchange overlapped with compute (rows
+                      split only).
     transport "host": all-reduce through pinned host memory and ``group`` (tests, rehearsal on one GPU).
     transport "auto": peer, else RCCL, else host -- after each attempt the ranks agree (one exchange of a flag
                       over ``group``) whether it worked everywhere, so the job never splits.
@@ -107,19 +108,20 @@ def attach_comm(ctx, group, transport="auto", shard_axis=0):
 
     if transport == "host":
         return host()
-    if transport == "rccl2":
-        # RCCL with the exchange cut into two column panels, the second overlapped with compute (NBMF_OVERLAP)
+    if transport in ("rccl2", "peer2"):
+        # the same transport with the exchange cut into two column panels, the second one travelling while the first
+        # is applied and the W-pass starts on its columns (NBMF_OVERLAP; rows split only)
         import os
         old = os.environ.get("NBMF_OVERLAP")
         os.environ["NBMF_OVERLAP"] = "1"
         try:
-            attach_comm(ctx, group, "rccl", shard_axis)
+            attach_comm(ctx, group, transport[:-1], shard_axis)
         finally:
             if old is None:
                 del os.environ["NBMF_OVERLAP"]
             else:
                 os.environ["NBMF_OVERLAP"] = old
-        return "rccl2"
+        return transport
     if transport not in ("peer", "rccl", "auto"):
         raise ValueError(f"unknown transport {transport!r}")
     errors = []
@@ -139,8 +141,8 @@ def attach_fastest(ctx, group, reset, shard_axis=0, candidates=("peer", "rccl"),
     every rank is timed over ``iters`` iterations (max over ranks) and detached again; the winner is attached
     for good (the host transport if none attaches).  ``reset()`` must restore the factors (``ctx.set_factors``)
     -- it is called before every trial and once more at the end.  Returns ``(transport, {name: seconds})``.
-    ("rccl2" may be added to ``candidates``; it is not a default because it keeps two collectives of one
-    communicator in flight on two streams, which has only been exercised with a single rank.)"""
+    ("peer2" and "rccl2" may be added to ``candidates``: the two-panel forms win once the exchange itself takes
+    longer than about 70 us, which only a machine with real links can tell.)"""
     import time
     timings = {}
     for name in candidates:

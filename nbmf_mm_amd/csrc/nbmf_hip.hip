@@ -306,6 +306,7 @@ struct nbmf_ctx {
   unsigned long long epoch = 0, hseq = 0;
   long long offHX = 0, offPR = 0, offSC = 0, x_doubles = 0;
   long long sl_c0 = 0, sl_wp = 0;   // axis 0: the column slice of H this rank updates
+  long long psl_c0[2] = {0, 0}, psl_wp[2] = {0, 0};   // ... per column panel when the exchange runs in two panels
   double *Pbuf_own = nullptr, *sbuf_own = nullptr, *Qbuf_own = nullptr;   // the private buffers while the arena stands in
   // the whole-fit-in-one-launch path for small problems (nbmf_small_kernel.inc): second parity of the factor
   // images, hand-off words, a snapshot of the factors for the fall-back
@@ -898,7 +899,7 @@ int enqueue_reduce_h_all(nbmf_ctx* c, double* dst, hipStream_t st) {
     hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st,
                        (const double*)(c->slabH + (size_t)sl * c->chunksH * per),
                        (const double*)(c->slabH + (size_t)(c->KS + sl) * c->chunksH * per), c->chunksH, (long long)per,
-                       (long long)c->nA, 0LL, (long long)c->nA, KSK, dst + sl * per, dst + tot + sl * per,
+                       (long long)c->nA, 0LL, (long long)c->nA, (long long)c->nA, KSK, dst + sl * per, dst + tot + sl * per,
                        (const double*)c->lossbuf, n_loss, ll_pad_of(c), sl == 0 ? dst + 2 * tot : (double*)nullptr, c->flags);
     HIPCHK(hipGetLastError());
   }
@@ -957,32 +958,85 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
       HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
     }
   }
-  double* X = c->arena;   // [P1 (KP x nA) | P2 (KP x nA) | loglik]
-  if (int rc = enqueue_reduce_h_all(c, X, c->stream)) return rc;
-  const unsigned long long e = ++c->epoch;
+  double* X = c->arena;   // [P1 (KP x nA) | P2 (KP x nA) | loglik], natural order
   const unsigned long long hs = ++c->hseq;
-  const int n_slots = PEER_H_WGS * c->pv.nranks;
-  const long long offPR_now = c->offPR + (long long)(hs & 1) * 2 * PEER_H_WGS * PEER_MAX_RANKS;
+  const int slots_per_panel = PEER_H_WGS * c->pv.nranks;
+  const long long offPR_now = c->offPR + (long long)(hs & 1) * 2 * 2 * PEER_H_WGS * PEER_MAX_RANKS;
   double* ll_slot = c->scal + 4;
-  // the loss and stop test of iteration it-1 ride in the same kernel (its first workgroup): they read the
+  // the loss and stop test of iteration it-1 ride in the exchange kernel (its first workgroup): they read the
   // prior sums the PREVIOUS exchange left in the arena
   const long long offPR_prev = c->prior_src ? (long long)(c->prior_src - c->arena) : 0;
   const bool prev_in_arena = c->prior_src >= c->arena && c->prior_src < c->arena + c->arena_doubles;
   const int fin_t = (it > 0 && prev_in_arena) ? it - 1 : -1;
-  hipLaunchKernelGGL(peer_h_kernel, dim3(PEER_H_WGS), dim3(256), 0, c->stream, c->pv, e, (long long)per, (long long)(2 * per),
-                     c->offHX, offPR_now, PEER_H_WGS * c->pv.rank, c->sl_c0, c->sl_wp, (const double*)c->Hn, c->k, c->KP,
-                     (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, ll_slot, c->flags, fin_t,
-                     offPR_prev, c->n_prior_src, c->n_obs_global, c->losses_d, tol, c->scal);
-  HIPCHK(hipGetLastError());
+  const int n_loss = c->chunksH * (a.Cb / WG_WAVES);
+  // One column panel [pc0[p], pc0[p+1]) of the H-step on stream `st`: ordered slab sum into the arena, then the
+  // fused reduce-scatter + Beta-MAP update + broadcast of this rank's slice of the panel (flag slot p).
+  auto exchange_panel = [&](int p, hipStream_t st, unsigned long long e) -> int {
+    const long long c0 = c->pc0[p], wp = c->pc0[p + 1] - c0;
+    if (c->KS > 1) {
+      if (int rc = enqueue_reduce_h_all(c, X, st)) return rc;   // (slices: one panel, see comm_finish_init)
+    } else {
+      hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)(((long long)c->KP * wp + 255) / 256)), dim3(256), 0, st,
+                         (const double*)a.out1, (const double*)a.out2, c->chunksH, (long long)per, (long long)c->nA, c0, wp,
+                         (long long)c->nA, c->KP, X + c0, X + per + c0, (const double*)c->lossbuf, n_loss, ll_pad_of(c),
+                         p == 0 ? X + 2 * per : (double*)nullptr, c->flags);
+      HIPCHK(hipGetLastError());
+    }
+    PeerView pv = c->pv;
+    pv.fbase = p * PF_SLOT;
+    hipLaunchKernelGGL(peer_h_kernel, dim3(PEER_H_WGS), dim3(256), 0, st, pv, e, (long long)per, p == 0 ? (long long)(2 * per) : -1LL,
+                       c->offHX, offPR_now, p * slots_per_panel + PEER_H_WGS * c->pv.rank, c->psl_c0[p], c->psl_wp[p],
+                       (const double*)c->Hn, c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps,
+                       ll_slot, c->flags, p == 0 ? fin_t : -1, offPR_prev, c->n_prior_src, c->n_obs_global, c->losses_d, tol,
+                       c->scal);
+    HIPCHK(hipGetLastError());
+    return NBMF_OK;
+  };
+  auto apply_panel = [&](int p, hipStream_t st, unsigned long long e) -> int {
+    PeerView pv = c->pv;
+    pv.fbase = p * PF_SLOT;
+    hipLaunchKernelGGL(peer_h_apply_kernel, dim3(PEER_H_WGS), dim3(256), 0, st, pv, e, c->offHX, c->Hn, c->HT, c->HG, c->KP,
+                       std::min(c->KP, SLICE_K), (long long)c->nA, c->pc0[p], c->pc0[p + 1] - c->pc0[p], c->flags);
+    HIPCHK(hipGetLastError());
+    return NBMF_OK;
+  };
+  const bool two = c->npanel == 2 && c->stream2;
+  hipStream_t s0 = c->stream, s1 = two ? c->stream2 : c->stream;
+  const unsigned long long e0 = ++c->epoch, e1 = two ? ++c->epoch : 0;
+  // ---- panel 0 (with the log-likelihood, the loss and the stop test of iteration it-1) on the main stream
+  if (int rc = exchange_panel(0, s0, e0)) return rc;
   c->ll_ptr = ll_slot;
   if (it > 0 && fin_t < 0)
     if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;   // (first iteration after nbmf_set_factors: local prior sums)
-  hipLaunchKernelGGL(peer_h_apply_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, c->stream, c->pv, e, c->offHX,
-                     c->Hn, c->HT, c->HG, c->KP, std::min(c->KP, SLICE_K), (long long)c->nA, c->flags);
-  HIPCHK(hipGetLastError());
   c->prior_src = c->arena + offPR_now;
-  c->n_prior_src = n_slots;
-  return enqueue_w_step(c, c->projection);   // the rows of W are local: no exchange in the W-step
+  c->n_prior_src = c->npanel * slots_per_panel;
+  if (!two) {
+    if (int rc = apply_panel(0, s0, e0)) return rc;
+    return enqueue_w_step(c, c->projection);   // the rows of W are local: no exchange in the W-step
+  }
+  // ---- two panels: panel 1's exchange travels on the side stream while panel 0 is applied and the W-pass sweeps
+  //      the chunks that read only panel 0's columns of H' (it is chunked over exactly that index); panel 1's H'
+  //      is applied behind the stop test and feeds the remaining chunks there.
+  // (panel 1's exchange kernel starts behind panel 0's, which settles the stop flag of iteration it-1: every rank
+  //  must see the same flag when its kernel decides whether to take part, or the others wait for it in vain)
+  HIPCHK(hipEventRecord(c->evF, s0));
+  HIPCHK(hipStreamWaitEvent(s1, c->evF, 0));
+  if (int rc = exchange_panel(1, s1, e1)) return rc;
+  if (int rc = apply_panel(1, s1, e1)) return rc;
+  PassArgs w = w_pass_args(c);
+  {
+    PassArgs w1 = w;
+    w1.chunk0 = c->wsplit;
+    HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, w1, c->chunksW - c->wsplit, s1));
+    HIPCHK(hipEventRecord(c->ev1, s1));
+  }
+  if (int rc = apply_panel(0, s0, e0)) return rc;
+  {
+    EvScope ev(c, 1);   // until both halves are done (includes any wait for panel 1's exchange)
+    HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, w, c->wsplit, s0));
+    HIPCHK(hipStreamWaitEvent(s0, c->ev1, 0));
+  }
+  return enqueue_w_update(c, c->slabW, c->chunksW, (double)c->n, c->projection);
 }
 
 // One whole iteration when the ROWS of Y are split over the ranks.  The exchange [P1 | P2 | loglik] is
@@ -1039,7 +1093,7 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
     double* d1 = c->Pbuf + c->pbase[p];
     double* d2 = d1 + (size_t)c->KP * wp;
     hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)(((long long)c->KP * wp + 255) / 256)), dim3(256), 0, st,
-                       (const double*)a.out1, (const double*)a.out2, c->chunksH, (long long)per, (long long)c->nA, c0, wp,
+                       (const double*)a.out1, (const double*)a.out2, c->chunksH, (long long)per, (long long)c->nA, c0, wp, wp,
                        c->KP, d1, d2, (const double*)c->lossbuf, n_loss, ll_pad_of(c),
                        p == 0 ? c->Pbuf + c->ll_index : (double*)nullptr, c->flags);
     HIPCHK(hipGetLastError());
@@ -2040,7 +2094,7 @@ static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   // with one rank, where there is nothing to hide); the break-even is an all-reduce of ~70 us, which cannot
   // be timed on a one-GPU box, so the default stays one panel.
   const char* ov = getenv("NBMF_OVERLAP");
-  c->npanel = (shard_axis == 0 && !c->peer && c->KS == 1 && c->chunksW >= 2 && ov && atoi(ov) != 0) ? 2 : 1;
+  c->npanel = (shard_axis == 0 && c->KS == 1 && c->chunksW >= 2 && ov && atoi(ov) != 0) ? 2 : 1;
   c->wsplit = c->npanel == 2 ? c->chunksW / 2 : c->chunksW;
   c->pc0[0] = 0;
   c->pc0[1] = c->npanel == 2 ? (long long)c->bW_host[c->wsplit] * 16 : c->nA;
@@ -2052,11 +2106,20 @@ static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
     fprintf(stderr, "[nbmf] rank %d/%d axis %d: %d exchange panel(s), columns split at %lld of %lld, W-pass chunks %d + %d, %s\n",
             rank, nranks, shard_axis, c->npanel, c->pc0[1], (long long)c->nA, c->wsplit, c->chunksW - c->wsplit,
             c->comm ? "RCCL" : c->peer ? "peer (xGMI)" : "host transport");
-  if (c->npanel == 2 && c->comm && !c->stream2) {
+  if (c->npanel == 2 && (c->comm || c->peer) && !c->stream2) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->evH, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->evF, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev1, hipEventDisableTiming));
+  }
+  if (c->peer && shard_axis == 0) {
+    // the slice of each panel's columns this rank reduces and updates, in 16-column blocks
+    for (int p = 0; p < c->npanel; ++p) {
+      const long long b_lo = c->pc0[p] / 16, nb = (c->pc0[p + 1] - c->pc0[p]) / 16;
+      const long long b0 = nb * rank / nranks, b1 = nb * (rank + 1) / nranks;
+      c->psl_c0[p] = 16 * (b_lo + b0);
+      c->psl_wp[p] = 16 * (b1 - b0);
+    }
   }
   if (shard_axis == 1 && !c->Qbuf) HIPCHK(hipMalloc(&c->Qbuf, sizeof(double) * (size_t)c->KP * c->mA));
   // global observed count (the divisor of _solver.py:162) and, when the columns are split, the global
@@ -2133,7 +2196,7 @@ static void peer_layout(nbmf_ctx* c, int axis) {
     c->x_doubles = 2 * fh + 8;
     c->offHX = c->x_doubles;
     c->offPR = c->offHX + fh;
-    c->offSC = c->offPR + 2LL * 2 * PEER_H_WGS * PEER_MAX_RANKS;
+    c->offSC = c->offPR + 2LL * 2 * 2 * PEER_H_WGS * PEER_MAX_RANKS;   // [parity][panel][workgroup of every rank][2]
   } else {
     c->x_doubles = fw + 8;
     c->offHX = c->offPR = c->offSC = c->x_doubles;
@@ -2226,27 +2289,30 @@ int nbmf_comm_init_peer(nbmf_ctx* c, const void* handles, int nranks, int rank, 
     c->sl_c0 = 16 * b0;
     c->sl_wp = 16 * (b1 - b0);
   }
-  // Known-answer exchange before anything depends on the transport: rank r contributes (r+1)*(i%1021+1)+t,
-  // all exact in binary64, twice with different data (also the first rendezvous of the ranks).
+  // Known-answer exchanges before anything depends on the transport (also the first rendezvous of the ranks):
+  // rank r contributes (r+1)*((i+7t)%1021+1)+t, all exact in binary64; FOUR epochs are queued back to back, each
+  // filling, reducing and checking on the device with no host synchronisation in between, so the arena and the
+  // flag words are reused exactly as consecutive iterations of a run reuse them.
   {
-    const size_t cnt = (size_t)std::min<long long>(c->x_doubles, 1 << 20);
-    std::vector<double> h(cnt);
+    const long long cnt = std::min<long long>(c->x_doubles, 1 << 20);
     const unsigned long long full = c->pv.timeout;
     c->pv.timeout = std::min<unsigned long long>(full, 10ull * 100000000ull);
-    for (int t = 0; t < 2; ++t) {
-      for (size_t i = 0; i < cnt; ++i) h[i] = (double)(rank + 1) * (double)(i % 1021 + 1) + t;
-      HIPCHK(hipMemcpyAsync(c->arena, h.data(), cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
-      if (int rc = all_reduce_inplace(c, c->arena, cnt)) return rc;
-      HIPCHK(hipMemcpyAsync(h.data(), c->arena, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      if (int rc = peer_check(c)) return rc;
-      const double tri = 0.5 * nranks * (nranks + 1);
-      for (size_t i = 0; i < cnt; ++i)
-        if (h[i] != tri * (double)(i % 1021 + 1) + (double)t * nranks)
-          return fail(NBMF_ERR_COMM, "peer transport self-test failed at element %zu (got %.17g)", i, h[i]);
+    unsigned long long* bad = c->stats + 4;
+    HIPCHK(hipMemsetAsync(bad, 0, sizeof(unsigned long long), c->stream));
+    for (int t = 0; t < 4; ++t) {
+      hipLaunchKernelGGL(peer_selftest_fill_kernel, dim3(256), dim3(256), 0, c->stream, c->arena, cnt, rank, t);
+      HIPCHK(hipGetLastError());
+      if (int rc = all_reduce_inplace(c, c->arena, (size_t)cnt)) return rc;
+      hipLaunchKernelGGL(peer_selftest_check_kernel, dim3(256), dim3(256), 0, c->stream, (const double*)c->arena, cnt, nranks, t, bad);
+      HIPCHK(hipGetLastError());
     }
+    unsigned long long n_bad = 0;
+    HIPCHK(hipMemcpyAsync(&n_bad, bad, sizeof n_bad, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (int rc = peer_check(c)) return rc;
+    if (n_bad) return fail(NBMF_ERR_COMM, "peer transport self-test failed: %llu wrong elements over four back-to-back exchanges", n_bad);
     c->pv.timeout = full;
-    HIPCHK(hipMemsetAsync(c->arena, 0, cnt * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->arena, 0, (size_t)cnt * sizeof(double), c->stream));
   }
   if (int rc = comm_finish_init(c, nranks, rank, shard_axis)) return rc;
   if (int rc = peer_check(c)) return rc;

@@ -44,7 +44,7 @@ def _setup(rank, world, port):
     return _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
 
 
-def _worker_rows(rank, world, port, q):
+def _worker_rows(rank, world, port, q, transport="peer"):
     dist = _setup(rank, world, port)
     from nbmf_mm_amd import _dist
     try:
@@ -53,7 +53,7 @@ def _worker_rows(rank, world, port, q):
         out = {}
         for name, kw in [("tol0", dict(max_iter=30, tol=0)), ("stop", dict(max_iter=400, tol=1e-4))]:
             out[name] = _dist.fit_row_sharded(Y[r0:r1], M, r0, K, dist, alpha=1.2, beta=1.3, mask_local=mask[r0:r1],
-                                              random_state=5, device=0, transport="peer", **kw)
+                                              random_state=5, device=0, transport=transport, **kw)
         q.put((rank, r0, r1, out))
     finally:
         dist.close()
@@ -74,13 +74,14 @@ def _run(target, world, *extra):
     return res
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_shards_peer_transport(world):
+@pytest.mark.parametrize("world,transport", [(2, "peer"), (3, "peer"), (2, "peer2"), (3, "peer2")])
+def test_row_shards_peer_transport(world, transport):
     """Fused reduce-scatter + H-update + broadcast: factors and loss curve of the single-process run, the
-    replicated factor bitwise equal on all ranks, and the stop rule firing at the same iteration."""
+    replicated factor bitwise equal on all ranks, and the stop rule firing at the same iteration.  "peer2": the
+    exchange in two column panels on two streams (two flag slots), the second overlapped with the W-pass."""
     from nbmf_mm_amd import nbmf_mm_solver
     from oracle import nbmf_oracle as orc
-    res = _run(_worker_rows, world)
+    res = _run(_worker_rows, world, transport)
     M, N, K, Y, mask = _problem()
     W1, H1, l1, _, n1 = nbmf_mm_solver(Y, K, max_iter=30, tol=0, alpha=1.2, beta=1.3, mask=mask, random_state=5)
     Wr, Hr, lr, _, _ = orc.solve(Y, K, max_iter=30, tol=0, alpha=1.2, beta=1.3, mask=mask, random_state=5)
