@@ -476,13 +476,14 @@ hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
   return hipGetLastError();
 }
 
-// n_components > 128: the sweep of one slice with Theta read from memory (TH = 1), and the Theta sweep itself
-template <int MODE>
+// n_components > 128: the sweep of one slice with Theta read from memory (TH = 1: whole; TH = 2: the earlier
+// slices' part, completed and stored here), and the Theta sweep itself
+template <int MODE, int TH>
 hipError_t launch_pass_slice(int data_kind, const PassArgs& a, int chunks, hipStream_t st) {
   switch (data_kind) {
-    case DATA_BIN: return launch_pass_t<8, DATA_BIN, MODE, 1>(a, chunks, st);
-    case DATA_F64: return launch_pass_t<8, DATA_F64, MODE, 1>(a, chunks, st);
-    case DATA_F64M: return launch_pass_t<8, DATA_F64M, MODE, 1>(a, chunks, st);
+    case DATA_BIN: return launch_pass_t<8, DATA_BIN, MODE, TH>(a, chunks, st);
+    case DATA_F64: return launch_pass_t<8, DATA_F64, MODE, TH>(a, chunks, st);
+    case DATA_F64M: return launch_pass_t<8, DATA_F64M, MODE, TH>(a, chunks, st);
   }
   return hipErrorInvalidValue;
 }
@@ -687,10 +688,11 @@ int enqueue_exchange_after_sweep(nbmf_ctx* c, const PassArgs& a, bool with_produ
 }
 
 // ---- n_components > 128: slices of SLICE_K components --------------------------------
-// Theta of the current factors into c->theta, in the tile order of image A (image 0: H-pass and loglik
-// sweeps) or image B (image 1: W-pass): one Theta-only sweep per slice, each adding onto the previous ones.
+// Theta of the current factors WITHOUT the last slice's part into c->theta, in the tile order of image A (image
+// 0: H-pass and loglik sweeps) or image B (image 1: W-pass): one Theta-only sweep per slice, each adding onto the
+// previous ones.
 int enqueue_theta(nbmf_ctx* c, int image) {
-  for (int sl = 0; sl < c->KS; ++sl) {
+  for (int sl = 0; sl < c->KS - 1; ++sl) {   // (the last slice's part is added by that slice's own fused sweep)
     const size_t offW = (size_t)sl * SLICE_K * c->mA, offH = (size_t)sl * SLICE_K * c->nA;
     PassArgs a{};
     a.LT = image == 0 ? c->WT + offW : c->HT + offH;
@@ -711,20 +713,25 @@ int enqueue_theta(nbmf_ctx* c, int image) {
   return NBMF_OK;
 }
 
-// the sweep of every slice over image A with Theta read back: back-products (with_products) or loglik only
+// The sweeps over image A of a sliced run: back-products (with_products) of every slice, or the log-likelihood
+// only.  Order: Theta-only sweeps of slices 0 .. KS-2; the LAST slice's sweep completes Theta from what they
+// stored, stores the total, reports the likelihood and forms its own products; then the other slices' sweeps
+// read the total.  (Theta crosses HBM 24 KS - 16 bytes per entry instead of 24 KS - 8, in one sweep fewer.)
 int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int clip) {
   if (int rc = enqueue_theta(c, 0)) return rc;
   const size_t per = (size_t)SLICE_K * c->nA;
-  for (int sl = 0; sl < (with_products ? c->KS : 1); ++sl) {
+  const int last = c->KS - 1;
+  for (int step = 0; step < (with_products ? c->KS : 1); ++step) {
+    const int sl = step == 0 ? last : step - 1;
     PassArgs a{};
     a.data = c->dataA;
     a.mask = c->maskA;
-    a.LT = c->WT;
+    a.LT = c->WT + (size_t)sl * SLICE_K * c->mA;
     a.LG = c->WG + (size_t)sl * SLICE_K * c->mA;
-    a.RfT = c->HT;
+    a.RfT = c->HT + (size_t)sl * SLICE_K * c->nA;
     a.out1 = c->slabH + (size_t)sl * c->chunksH * per;
     a.out2 = c->slabH + (size_t)(c->KS + sl) * c->chunksH * per;
-    a.lossbuf = sl == 0 ? c->lossbuf : nullptr;   // the likelihood is the same in every slice's sweep
+    a.lossbuf = step == 0 ? c->lossbuf : nullptr;   // the likelihood is the same in every slice's sweep
     a.done = c->flags;
     a.Rb = (int)(c->mA / 16);
     a.Cb = (int)(c->nA / 16);
@@ -732,14 +739,16 @@ int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int cli
     a.C_alloc = c->nA;
     a.eps = c->eps;
     a.tiny_eps = c->eps < 1e-70;
-  a.tiny_eps = c->eps < 1e-70;
     a.strict = strict;
     a.clip = clip;
     a.theta = c->theta;
+    hipError_t e;
     if (with_products)
-      HIPCHK(launch_pass_slice<MODE_H>(c->data_kind, a, c->chunksH, c->stream));
+      e = step == 0 ? launch_pass_slice<MODE_H, 2>(c->data_kind, a, c->chunksH, c->stream)
+                    : launch_pass_slice<MODE_H, 1>(c->data_kind, a, c->chunksH, c->stream);
     else
-      HIPCHK(launch_pass_slice<MODE_L>(c->data_kind, a, c->chunksH, c->stream));
+      e = launch_pass_slice<MODE_L, 2>(c->data_kind, a, c->chunksH, c->stream);
+    HIPCHK(e);
   }
   return NBMF_OK;
 }
@@ -1155,12 +1164,18 @@ int enqueue_w_step(nbmf_ctx* c, int projection) {
     {
       EvScope ev(c, 1);
       if (int rc = enqueue_theta(c, 1)) return rc;
-      for (int sl = 0; sl < c->KS; ++sl) {
+      for (int step = 0; step < c->KS; ++step) {   // the last slice first: it completes and stores Theta'
+        const int sl = step == 0 ? c->KS - 1 : step - 1;
         PassArgs w = w_pass_args(c);
+        w.LT = c->HT + (size_t)sl * SLICE_K * c->nA;
         w.LG = c->HG + (size_t)sl * SLICE_K * c->nA;
+        w.RfT = c->WT + (size_t)sl * SLICE_K * c->mA;
         w.out1 = c->slabW + (size_t)sl * c->chunksW * SLICE_K * c->mA;
         w.theta = c->theta;
-        HIPCHK(launch_pass_slice<MODE_W>(c->data_kind, w, c->chunksW, c->stream));
+        if (step == 0)
+          HIPCHK((launch_pass_slice<MODE_W, 2>(c->data_kind, w, c->chunksW, c->stream)));
+        else
+          HIPCHK((launch_pass_slice<MODE_W, 1>(c->data_kind, w, c->chunksW, c->stream)));
       }
     }
     if (is_sharded(c) && c->shard_axis == 1) {
