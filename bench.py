@@ -119,6 +119,40 @@ def profiled_traffic(M, N, K, masked, world):
     return None, None
 
 
+def verify_transport(ctx, group, reset, transport, iters=3):
+    """The attached transport against the host transport (sums through pinned host memory, formed in rank order):
+    `iters` iterations from the same state must give the same losses and the same replicated factor to rounding.
+    Setup work, untimed.  A transport that fails is replaced by RCCL (then the host transport), and the line says so:
+    the library's own exchange kernels have only ever been run between processes sharing one GPU, so the first run
+    over real links checks itself.  Returns (transport in use, verdict string)."""
+    from nbmf_mm_amd import _dist
+
+    def curve():
+        reset()
+        losses, _ = ctx.run(iters, 0.0)
+        return np.array(losses), ctx.get_factors()[1]
+
+    try:
+        la, Ha = curve()
+        ok = True
+    except Exception:                       # a timed-out exchange: NBMFHipError
+        la, Ha, ok = None, None, False
+    ctx.comm_detach()
+    _dist.attach_comm(ctx, group, "host")
+    lb, Hb = curve()
+    ctx.comm_detach()
+    if ok:
+        ok = bool(np.allclose(la, lb, rtol=1e-12, atol=0) and np.allclose(Ha, Hb, rtol=0, atol=1e-12))
+    ok = group.agree(ok)
+    if ok:
+        _dist.attach_comm(ctx, group, transport)
+        reset()
+        return transport, "equals the host transport to 1e-12 over %d iterations" % iters
+    used = _dist.attach_comm(ctx, group, "rccl" if not transport.startswith("rccl") else "host")
+    reset()
+    return used, f"{transport} DISAGREED with the host transport and was replaced by {used}"
+
+
 def launch_ranks(n):
     """`bench.py --gpus N` invoked plainly: start N children of this script, one per GPU, BEFORE this process
     has touched a GPU (it never does), wait for them, and pass on the worst exit code.  Rank 0's child prints
@@ -180,6 +214,8 @@ def main():
                     help="attach a 1-rank communicator (RCCL, or the peer transport with --transport peer) even with --gpus 1: "
                          "the sharded code path and its per-iteration overhead, minus the wires")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal on a 1-GPU box)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the untimed check of the chosen transport against the host transport (--gpus > 1)")
     args = ap.parse_args()
 
     if args.overlap:
@@ -233,13 +269,16 @@ def main():
         ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
 
     reset()
-    transport, trials = "none", None
+    transport, trials, transport_check = "none", None, None
     if world > 1:
         if args.transport == "auto":
             # time a few iterations over each transport that attaches and keep the faster one (setup, untimed)
             transport, trials = _dist.attach_fastest(ctx, group, reset, candidates=("peer", "peer2", "rccl"))
         else:
             transport = _dist.attach_comm(ctx, group, args.transport)
+        transport_check = None
+        if transport != "host" and not args.no_verify:
+            transport, transport_check = verify_transport(ctx, group, reset, transport)
     elif args.force_comm:
         if args.transport == "peer":
             ctx.comm_init_peer(ctx.peer_export(0), 1, 0)
@@ -312,7 +351,7 @@ def main():
                                "(_solver.py:54,57) timed in the same run on the same data",
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
                        "devices": devices,
-                       "transport_trials_s_per_5_iterations": trials,
+                       "transport_trials_s_per_5_iterations": trials, "transport_check": transport_check,
                        "sharding": (f"rows/{world} ({transport}: " + ("reduce-scatter of 2*K*N+1 doubles fused with the H-update, K*N back"
                                                              if transport.startswith("peer") else "all-reduce of 2*K*N+1 doubles"
                                                              + (" in two overlapped panels" if transport.endswith("2") else ""))
