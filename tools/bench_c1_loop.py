@@ -10,7 +10,8 @@ CASES = [("configs[0] 100x500 K=6", 100, 500, 6), ("animals 50x85 K=4", 50, 85, 
          ("lastfm 1226x285 K=8", 1226, 285, 8), ("lastfm 1226x285 K=16", 1226, 285, 16), ("1024x1024 K=16", 1024, 1024, 16),
          ("1024x1024 K=32", 1024, 1024, 32), ("2000x2000 K=16", 2000, 2000, 16)]
 its = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-for name, m, n, k in CASES:
+only = sys.argv[2] if len(sys.argv) > 2 else ""
+for name, m, n, k in [c for c in CASES if only in c[0]]:
     X = (np.random.default_rng(0).random((m, n)) < 0.25).astype(np.float64)
     W, H = _dist.global_init(m, n, k, random_state=0)
     row = []
