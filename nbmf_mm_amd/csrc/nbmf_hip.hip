@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -243,6 +244,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ------------------------------------------------------------------------------------------
 struct nbmf_ctx {
   int device = 0;
+  int cus = 256;            // compute units of the device (read once at creation)
   hipStream_t stream = nullptr;
   int64_t m = 0, n = 0, mA = 0, nA = 0;
   int k = 0, KP = 0, KB = 0;
@@ -315,6 +317,7 @@ struct nbmf_ctx {
     double *snapW = nullptr, *snapH = nullptr, *ll_part = nullptr, *prior_part = nullptr;
     unsigned long long* sync = nullptr;
     int* result = nullptr;
+    char* slab = nullptr;        // the one allocation behind all of the above
     bool ready = false, disabled = false;
     int runs = 0, aborted = 0;   // statistics (nbmf_small_stats)
   } small;
@@ -1249,22 +1252,61 @@ bool small_eligible(const nbmf_ctx* c, int cus) {
   return Rbe <= cap && Cbe <= cap && std::max(Rbe, Cbe) <= cus && Rbe * Cbe <= max_tiles;
 }
 
+// Admission of persistent kernels, per device and process-wide: a persistent kernel needs ALL its workgroups
+// resident (one per CU) or its first barrier never completes.  Several host threads may run small fits on one GPU
+// at once (experiments.perplexity_grid(concurrency=...)); launched together, their kernels would each get a share
+// of the CUs and wait for the rest forever.  So a run reserves its CUs first and waits (milliseconds: these runs
+// are short) while the ones in flight hold too many.
+struct SmallAdmission {
+  std::mutex mu;
+  std::condition_variable cv;
+  int busy[64] = {0};
+} g_small_admission;
+
+struct SmallReservation {
+  int device, n;
+  SmallReservation(int device_, int n_, int capacity) : device(device_ & 63), n(n_) {
+    std::unique_lock<std::mutex> lk(g_small_admission.mu);
+    g_small_admission.cv.wait(lk, [&] { return g_small_admission.busy[device] + n <= capacity || g_small_admission.busy[device] == 0; });
+    g_small_admission.busy[device] += n;
+  }
+  ~SmallReservation() {
+    {
+      std::lock_guard<std::mutex> lk(g_small_admission.mu);
+      g_small_admission.busy[device] -= n;
+    }
+    g_small_admission.cv.notify_all();
+  }
+};
+
 int small_prepare(nbmf_ctx* c) {
   if (c->small.ready) return NBMF_OK;
+  // one allocation carved up (a fit of a small problem is over in milliseconds: a dozen hipMallocs would show)
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
-  for (double** p : {&c->small.Wn, &c->small.WT, &c->small.WG, &c->small.snapW}) {
-    HIPCHK(hipMalloc(p, fw));
-    HIPCHK(hipMemsetAsync(*p, 0, fw, c->stream));   // pad strips are never written: they must read as zero
-  }
-  for (double** p : {&c->small.Hn, &c->small.HT, &c->small.HG, &c->small.snapH}) {
-    HIPCHK(hipMalloc(p, fh));
-    HIPCHK(hipMemsetAsync(*p, 0, fh, c->stream));
-  }
   const size_t g_max = 16 * SM_TPW;
-  HIPCHK(hipMalloc(&c->small.sync, sizeof(unsigned long long) * (g_max + 8)));
-  HIPCHK(hipMalloc(&c->small.ll_part, sizeof(double) * g_max));                 // [strip]
-  HIPCHK(hipMalloc(&c->small.prior_part, sizeof(double) * 2 * g_max * 8 * 2));  // [parity][strip][updating wave][2]
-  HIPCHK(hipMalloc(&c->small.result, sizeof(int) * 4));
+  const size_t sync_b = round_up(sizeof(unsigned long long) * (g_max + 8), 256), ll_b = round_up(sizeof(double) * g_max, 256),
+               pr_b = sizeof(double) * 2 * g_max * 8 * 2, res_b = 256;
+  const size_t total = 4 * fw + 4 * fh + sync_b + ll_b + pr_b + res_b;
+  char* base = nullptr;
+  HIPCHK(hipMalloc(&base, total));
+  HIPCHK(hipMemsetAsync(base, 0, total, c->stream));   // (pad strips of the second set of images are never written: they must read as zero)
+  c->small.slab = base;
+  char* p = base;
+  for (double** q : {&c->small.Wn, &c->small.WT, &c->small.WG, &c->small.snapW}) {
+    *q = (double*)p;
+    p += fw;
+  }
+  for (double** q : {&c->small.Hn, &c->small.HT, &c->small.HG, &c->small.snapH}) {
+    *q = (double*)p;
+    p += fh;
+  }
+  c->small.sync = (unsigned long long*)p;   // [strip] epoch words + abort word
+  p += sync_b;
+  c->small.ll_part = (double*)p;            // [strip]
+  p += ll_b;
+  c->small.prior_part = (double*)p;         // [parity][strip][updating wave][2]
+  p += pr_b;
+  c->small.result = (int*)p;
   c->small.ready = true;
   return NBMF_OK;
 }
@@ -1273,10 +1315,7 @@ int small_prepare(nbmf_ctx* c) {
 // buffers); *handled = false means "use the five-kernel path" (factors restored to their state at entry).
 int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter, bool* handled) {
   *handled = false;
-  hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, c->device));
-  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (!small_eligible(c, cus)) return NBMF_OK;
+  if (!small_eligible(c, c->cus)) return NBMF_OK;
   if (int rc = small_prepare(c)) return rc;
   auto& w = c->small;
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
@@ -1334,6 +1373,7 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
     a.dbg = dbg;
   }
   void* params[] = {&a};
+  SmallReservation cus_held(c->device, a.G, c->cus);   // until this function returns (it synchronises the stream first)
   HIPCHK(hipLaunchKernel(f, dim3(a.G), dim3(64 * NW), params, lds_bytes, c->stream));
   if (dbg) {   // per-phase wall clock of workgroup 0 (10 ns ticks): tiles | update | barrier | tiles | update+loss | barrier
     unsigned long long h[64 * 16];
@@ -1415,9 +1455,7 @@ int ensure_losses(nbmf_ctx* c, int cap) {
 // Chunking of the two sweeps and the slabs that go with it; needs the storage path (it decides the
 // kernels' residency), so it runs at the end of nbmf_upload.
 int setup_workspaces(nbmf_ctx* c) {
-  hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, c->device));
-  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const int cus = c->cus;
   const int NB = 8 / c->KB;
   const int slotsH = cus * resident_per_cu<MODE_H>(c->KB, c->data_kind);
   const int slotsW = cus * resident_per_cu<MODE_W>(c->KB, c->data_kind);
@@ -1546,6 +1584,7 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
     return fail(NBMF_ERR_HIP, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
 
   nbmf_ctx* c = new nbmf_ctx();
+  c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   struct CtxGuard {   // a failure below releases what has been allocated so far
     nbmf_ctx* p;
     ~CtxGuard() {
@@ -1600,9 +1639,7 @@ int nbmf_destroy(nbmf_ctx* c) {
   arena_release((ArenaSlot*)c->arena_slot.p);   // back to the pool, never to the allocator (see ArenaSlot)
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
                   c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
-                  c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta, c->small.Wn, c->small.WT, c->small.WG, c->small.Hn,
-                  c->small.HT, c->small.HG, c->small.snapW, c->small.snapH, c->small.ll_part, c->small.prior_part,
-                  c->small.sync, c->small.result};
+                  c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta, c->small.slab};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (hipEvent_t e : c->ev) hipEventDestroy(e);
