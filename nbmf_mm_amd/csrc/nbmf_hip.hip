@@ -1284,8 +1284,8 @@ int small_prepare(nbmf_ctx* c) {
   // one allocation carved up (a fit of a small problem is over in milliseconds: a dozen hipMallocs would show)
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
   const size_t g_max = 16 * SM_TPW;
-  const size_t sync_b = round_up(sizeof(unsigned long long) * (g_max + 8), 256), ll_b = round_up(sizeof(double) * g_max, 256),
-               pr_b = sizeof(double) * 2 * g_max * 8 * 2, res_b = 256;
+  const size_t sync_b = round_up(sizeof(unsigned long long) * (g_max + 8), 256), ll_b = round_up(sizeof(double) * 2 * g_max, 256),
+               pr_b = sizeof(double) * 3 * g_max * 8 * 2, res_b = 256;
   const size_t total = 4 * fw + 4 * fh + sync_b + ll_b + pr_b + res_b;
   char* base = nullptr;
   HIPCHK(hipMalloc(&base, total));
@@ -1302,9 +1302,9 @@ int small_prepare(nbmf_ctx* c) {
   }
   c->small.sync = (unsigned long long*)p;   // [strip] epoch words + abort word
   p += sync_b;
-  c->small.ll_part = (double*)p;            // [strip]
+  c->small.ll_part = (double*)p;            // [parity][strip]
   p += ll_b;
-  c->small.prior_part = (double*)p;         // [parity][strip][updating wave][2]
+  c->small.prior_part = (double*)p;         // [iteration mod 3][strip][updating wave][2]
   p += pr_b;
   c->small.result = (int*)p;
   c->small.ready = true;
