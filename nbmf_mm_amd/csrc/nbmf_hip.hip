@@ -317,6 +317,8 @@ struct nbmf_ctx {
     double *snapW = nullptr, *snapH = nullptr, *ll_part = nullptr, *prior_part = nullptr;
     unsigned long long* sync = nullptr;
     int* result = nullptr;
+    double *part_buf = nullptr, *part_ll = nullptr;   // hand-off of split strips
+    unsigned long long* part_flag = nullptr;
     char* slab = nullptr;        // the one allocation behind all of the above
     bool ready = false, disabled = false;
     int runs = 0, aborted = 0;   // statistics (nbmf_small_stats)
@@ -1227,12 +1229,12 @@ __global__ void expand_factor_kernel(const double* __restrict__ Fn, double* __re
   FG[g_index(k, x, KS, lenA)] = Fn[idx];
 }
 
-template <int KB>
+template <int KB, bool SPLIT>
 const void* small_ptr(int data_kind) {
   switch (data_kind) {
-    case DATA_BIN: return (const void*)small_fit_kernel<KB, DATA_BIN>;
-    case DATA_F64: return (const void*)small_fit_kernel<KB, DATA_F64>;
-    case DATA_F64M: return (const void*)small_fit_kernel<KB, DATA_F64M>;
+    case DATA_BIN: return (const void*)small_fit_kernel<KB, DATA_BIN, SPLIT>;
+    case DATA_F64: return (const void*)small_fit_kernel<KB, DATA_F64, SPLIT>;
+    case DATA_F64M: return (const void*)small_fit_kernel<KB, DATA_F64M, SPLIT>;
   }
   return nullptr;
 }
@@ -1284,9 +1286,11 @@ int small_prepare(nbmf_ctx* c) {
   // one allocation carved up (a fit of a small problem is over in milliseconds: a dozen hipMallocs would show)
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
   const size_t g_max = 16 * SM_TPW;
-  const size_t sync_b = round_up(sizeof(unsigned long long) * (g_max + 8), 256), ll_b = round_up(sizeof(double) * 2 * g_max, 256),
+  const size_t sync_b = round_up(sizeof(unsigned long long) * (256 + 8), 256), ll_b = round_up(sizeof(double) * 2 * g_max, 256),
                pr_b = sizeof(double) * 3 * g_max * 8 * 2, res_b = 256;
-  const size_t total = 4 * fw + 4 * fh + sync_b + ll_b + pr_b + res_b;
+  const size_t g_all = 256;   // most workgroups a run can have (one per CU)
+  const size_t pb_b = sizeof(double) * g_all * 2 * 16 * (size_t)c->KP, pl_b = sizeof(double) * g_all, pf_b = sizeof(unsigned long long) * g_all;
+  const size_t total = 4 * fw + 4 * fh + sync_b + ll_b + pr_b + res_b + pb_b + pl_b + pf_b;
   char* base = nullptr;
   HIPCHK(hipMalloc(&base, total));
   HIPCHK(hipMemsetAsync(base, 0, total, c->stream));   // (pad strips of the second set of images are never written: they must read as zero)
@@ -1307,6 +1311,12 @@ int small_prepare(nbmf_ctx* c) {
   c->small.prior_part = (double*)p;         // [iteration mod 3][strip][updating wave][2]
   p += pr_b;
   c->small.result = (int*)p;
+  p += res_b;
+  c->small.part_buf = (double*)p;           // [workgroup][2][16 KP]
+  p += pb_b;
+  c->small.part_ll = (double*)p;
+  p += pl_b;
+  c->small.part_flag = (unsigned long long*)p;
   c->small.ready = true;
   return NBMF_OK;
 }
@@ -1338,7 +1348,29 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   a.CbA = (int)(c->nA / 16);
   a.Rbe = (int)((c->m + 15) / 16);
   a.Cbe = (int)((c->n + 15) / 16);
-  a.G = std::max(a.Rbe, a.Cbe);
+  // Strips whose sweep is long are split over several workgroups (a CU each): aim at two tiles per wave, stay within
+  // the CUs, at most 8 parts (one partner hand-off costs ~2 us: not worth it for shorter sweeps).
+  {
+    const int NWv = sm_waves(c->KB);
+    auto parts = [&](int sweep_blocks, int strips) {
+      int pp = (sweep_blocks + 2 * NWv - 1) / (2 * NWv);
+      pp = std::min(pp, std::min(8, c->cus / std::max(1, strips)));
+      return std::max(1, pp);
+    };
+    a.PH = parts(a.Rbe, a.Cbe);
+    a.PW = parts(a.Cbe, a.Rbe);
+    if (const char* e = getenv("NBMF_SMALL_PARTS")) {   // "ph,pw" (experiments)
+      int x = 0, y = 0;
+      if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 1 && y >= 1 && x <= 8 && y <= 8 && a.Cbe * x <= c->cus && a.Rbe * y <= c->cus) {
+        a.PH = x;
+        a.PW = y;
+      }
+    }
+  }
+  a.G = std::max(a.Cbe * a.PH, a.Rbe * a.PW);
+  a.part_buf = w.part_buf;
+  a.part_ll = w.part_ll;
+  a.part_flag = w.part_flag;
   a.max_iter = max_iter;
   a.projection = c->projection;
   a.tiny_eps = c->eps < 1e-70;
@@ -1352,7 +1384,9 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   double ms = 2000.0;
   if (const char* e = getenv("NBMF_SMALL_TIMEOUT_MS")) ms = std::max(1.0, atof(e));
   a.timeout = (unsigned long long)(ms * 1e5);
-  const void* f = c->KB == 1 ? small_ptr<1>(c->data_kind) : small_ptr<2>(c->data_kind);
+  const bool split = a.PH > 1 || a.PW > 1;
+  const void* f = c->KB == 1 ? (split ? small_ptr<1, true>(c->data_kind) : small_ptr<1, false>(c->data_kind))
+                             : (split ? small_ptr<2, true>(c->data_kind) : small_ptr<2, false>(c->data_kind));
   if (!f) return NBMF_OK;
   const int NW = sm_waves(c->KB);
   const size_t lds_bytes = sizeof(double) * ((size_t)NW * 2 * c->KB * 4 * 64 + NW * 16 + 64 + 2 * c->KP * 16) + LOG_TABLE_BYTES;
@@ -1361,6 +1395,7 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   HIPCHK(hipMemcpyAsync(w.snapW, c->Wn, fw, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(w.snapH, c->Hn, fh, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemsetAsync(w.sync, 0, sizeof(unsigned long long) * (a.G + 1), c->stream));
+  HIPCHK(hipMemsetAsync(w.part_flag, 0, sizeof(unsigned long long) * 256, c->stream));
   HIPCHK(hipMemsetAsync(w.result, 0, sizeof(int) * 4, c->stream));
   if (getenv("NBMF_SMALL_FORCE_ABORT")) {   // tests: raise the abort word up front, so that the fall-back runs
     const unsigned long long one = 1;
