@@ -1239,19 +1239,31 @@ const void* small_ptr(int data_kind) {
   return nullptr;
 }
 
+// How many workgroups a strip of the H-step (sweep of Rbe blocks, Cbe strips) or of the W-step is split over: aim at
+// two tiles per wave, stay within the CUs, at most 8 parts (one partner hand-off costs ~2 us: not worth it for
+// shorter sweeps).
+int small_parts(const nbmf_ctx* c, long long sweep_blocks, long long strips) {
+  const int NW = sm_waves(c->KB);
+  long long pp = (sweep_blocks + 2 * NW - 1) / (2 * NW);
+  pp = std::min<long long>(pp, std::min<long long>(8, c->cus / std::max<long long>(1, strips)));
+  return (int)std::max<long long>(1, pp);
+}
+
 // Is this run one for the persistent kernel?  One GPU, at most 32 components (the 16-wave workgroups leave 128
-// registers per lane), no per-launch instrumentation asked for, and few enough tiles that a wave sweeps at most
-// SM_TPW of them per phase -- beyond that (NBMF_SMALL_TILES, default 4096 tiles) the five-kernel path with its
-// LDS-staged panels is the faster one.
+// registers per lane), no per-launch instrumentation asked for, every workgroup on a CU of its own, at most SM_TPW
+// tiles per wave and phase, at most 128 H-strips (the loss is summed by one wave, two strips per lane) -- and not
+// more than NBMF_SMALL_TILES tiles (default 32768, which the other bounds imply anyway: at 4080 x 2040, K = 16 the
+// single launch still runs 1.4x the five-kernel path; larger problems belong to the LDS-staged pass kernels).
 bool small_eligible(const nbmf_ctx* c, int cus) {
   if (c->small.disabled || is_sharded(c) || c->KS != 1 || c->KB > 2 || c->timing || (c->progress && c->progress_every > 0)) return false;
   if (const char* e = getenv("NBMF_PERSISTENT"))
     if (atoi(e) == 0) return false;
   const long long Rbe = (c->m + 15) / 16, Cbe = (c->n + 15) / 16;
-  long long max_tiles = 4096;
+  long long max_tiles = 32768;
   if (const char* e = getenv("NBMF_SMALL_TILES")) max_tiles = atoll(e);
-  const long long cap = sm_waves(c->KB) * SM_TPW;
-  return Rbe <= cap && Cbe <= cap && std::max(Rbe, Cbe) <= cus && Rbe * Cbe <= max_tiles;
+  const int NW = sm_waves(c->KB), PH = small_parts(c, Rbe, Cbe), PW = small_parts(c, Cbe, Rbe);
+  const bool fits = (Rbe + (long long)PH * NW - 1) / ((long long)PH * NW) <= SM_TPW && (Cbe + (long long)PW * NW - 1) / ((long long)PW * NW) <= SM_TPW;
+  return fits && Cbe <= 128 && Cbe * PH <= cus && Rbe * PW <= cus && Rbe * Cbe <= max_tiles;
 }
 
 // Admission of persistent kernels, per device and process-wide: a persistent kernel needs ALL its workgroups
@@ -1348,23 +1360,14 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   a.CbA = (int)(c->nA / 16);
   a.Rbe = (int)((c->m + 15) / 16);
   a.Cbe = (int)((c->n + 15) / 16);
-  // Strips whose sweep is long are split over several workgroups (a CU each): aim at two tiles per wave, stay within
-  // the CUs, at most 8 parts (one partner hand-off costs ~2 us: not worth it for shorter sweeps).
-  {
-    const int NWv = sm_waves(c->KB);
-    auto parts = [&](int sweep_blocks, int strips) {
-      int pp = (sweep_blocks + 2 * NWv - 1) / (2 * NWv);
-      pp = std::min(pp, std::min(8, c->cus / std::max(1, strips)));
-      return std::max(1, pp);
-    };
-    a.PH = parts(a.Rbe, a.Cbe);
-    a.PW = parts(a.Cbe, a.Rbe);
-    if (const char* e = getenv("NBMF_SMALL_PARTS")) {   // "ph,pw" (experiments)
-      int x = 0, y = 0;
-      if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 1 && y >= 1 && x <= 8 && y <= 8 && a.Cbe * x <= c->cus && a.Rbe * y <= c->cus) {
-        a.PH = x;
-        a.PW = y;
-      }
+  // strips whose sweep is long are split over several workgroups, a CU each (small_parts)
+  a.PH = small_parts(c, a.Rbe, a.Cbe);
+  a.PW = small_parts(c, a.Cbe, a.Rbe);
+  if (const char* e = getenv("NBMF_SMALL_PARTS")) {   // "ph,pw" (experiments; must still satisfy small_eligible's bounds)
+    int x = 0, y = 0;
+    if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= a.PH && y >= a.PW && x <= 8 && y <= 8 && a.Cbe * x <= c->cus && a.Rbe * y <= c->cus) {
+      a.PH = x;
+      a.PW = y;
     }
   }
   a.G = std::max(a.Cbe * a.PH, a.Rbe * a.PW);
