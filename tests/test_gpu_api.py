@@ -310,3 +310,40 @@ def test_single_launch_path_serves_small_problems_and_falls_back_cleanly(monkeyp
     np.testing.assert_allclose(l, lr, rtol=1e-10, atol=0)
     np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-9)
     np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-9)
+
+
+def test_single_launch_hand_offs_are_reproducible(monkeypatch):
+    """The persistent kernel's workgroups hand the factors to each other through memory with write-through stores,
+    L1-bypassing loads and flag words instead of cache-maintenance fences: a stale read anywhere would show as a
+    run that differs from its repetitions.  Ten repetitions of long runs on shapes with unsplit and split strips,
+    bit for bit, and against the five-kernel path (tools/soak_small.py is the long form)."""
+    from nbmf_mm_amd import _hip
+    for (m, n, k, real, its) in [(100, 500, 6, False, 3000), (1226, 285, 8, False, 800), (253, 902, 12, True, 800),
+                                 (1000, 1000, 32, False, 300)]:
+        r = np.random.default_rng(1)
+        X = r.random((m, n)) if real else (r.random((m, n)) < 0.25).astype(np.float64)
+        mask = r.random((m, n)) < 0.9
+        W0 = r.uniform(0.1, 0.9, (k, m))
+        W0 /= W0.sum(axis=0, keepdims=True)
+        H0 = r.uniform(0.1, 0.9, (k, n))
+        monkeypatch.setenv("NBMF_PERSISTENT", "0")
+        with _hip.Context(m, n, k) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            ctx.upload(X, mask=mask)
+            ctx.set_factors(W0, H0)
+            lref, _ = ctx.run(its, 0.0)
+        monkeypatch.setenv("NBMF_PERSISTENT", "1")
+        with _hip.Context(m, n, k) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            ctx.upload(X, mask=mask)
+            first = None
+            for _ in range(10):
+                ctx.set_factors(W0, H0)
+                l, _ = ctx.run(its, 0.0)
+                out = (l,) + ctx.get_factors()
+                if first is None:
+                    first = out
+                for a, b in zip(out, first):
+                    np.testing.assert_array_equal(a, b)
+            assert ctx.small_stats() == (10, 0)
+        np.testing.assert_allclose(l, lref, rtol=1e-12, atol=0)
