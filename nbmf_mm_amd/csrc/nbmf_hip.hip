@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -337,6 +338,136 @@ struct nbmf_ctx {
 };
 
 namespace {
+
+// ---- device memory: a small caching allocator ---------------------------------------------------
+// A fit of one of the reference's datasets is over in 2-3 ms; creating and destroying its context cost more than
+// that in hipMalloc / hipFree calls (measured: 1.9 + 1.4 ms at 100 x 500, K = 6).  Blocks of up to 64 MiB are
+// therefore kept on release -- per device, by exact size, up to NBMF_POOL_MB (default 1024) in total -- and handed to
+// the next context that asks for that size.  A context synchronises its stream before it releases anything, so a
+// reused block is never still in use; nothing relies on fresh memory being zero (every buffer is written or cleared
+// before it is read).
+struct DevPool {
+  std::mutex mu;
+  struct Key {
+    int device;
+    size_t bytes;
+    bool operator<(const Key& o) const { return device != o.device ? device < o.device : bytes < o.bytes; }
+  };
+  std::multimap<Key, void*> free_blocks;
+  std::map<void*, Key> live;     // every block handed out (pooled or not), for dfree to find its size
+  size_t held = 0;
+} g_pool;
+
+template <typename T>
+hipError_t dmalloc(T** out, size_t bytes) {
+  *out = nullptr;
+  if (bytes == 0) bytes = 256;
+  int dev = 0;
+  hipGetDevice(&dev);
+  const DevPool::Key key{dev, (bytes + 255) / 256 * 256};
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.free_blocks.find(key);
+    if (it != g_pool.free_blocks.end()) {
+      *out = (T*)it->second;
+      g_pool.held -= key.bytes;
+      g_pool.free_blocks.erase(it);
+      g_pool.live[(void*)*out] = key;
+      return hipSuccess;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, key.bytes);
+  if (e != hipSuccess) {   // out of memory: give back what is held and try once more
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> lk(g_pool.mu);
+      for (auto& kv : g_pool.free_blocks) drop.push_back(kv.second);
+      g_pool.free_blocks.clear();
+      g_pool.held = 0;
+    }
+    for (void* q : drop) hipFree(q);
+    e = hipMalloc(&p, key.bytes);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  g_pool.live[p] = key;
+  *out = (T*)p;
+  return hipSuccess;
+}
+
+hipError_t dfree(void* p) {
+  if (!p) return hipSuccess;
+  static const size_t cap = [] {
+    const char* e = getenv("NBMF_POOL_MB");
+    return (size_t)(e ? std::max(0, atoi(e)) : 1024) << 20;
+  }();
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.live.find(p);
+    if (it != g_pool.live.end()) {
+      const DevPool::Key key = it->second;
+      g_pool.live.erase(it);
+      if (key.bytes <= (64u << 20) && g_pool.held + key.bytes <= cap) {
+        g_pool.free_blocks.emplace(key, p);
+        g_pool.held += key.bytes;
+        return hipSuccess;
+      }
+    }
+  }
+  return hipFree(p);
+}
+
+// ... and the same for what else a context needs from the runtime: device properties are read once per device and
+// process (hipGetDeviceProperties takes ~1 ms), streams are kept on release and reused (create + destroy ~1 ms).
+struct DevInfo {
+  bool known = false, gfx950 = false;
+  int cus = 256;
+  char arch[64] = {0};
+};
+DevInfo g_devinfo[64];
+std::mutex g_devinfo_mu;
+
+hipError_t device_info(int device, DevInfo* out) {
+  std::lock_guard<std::mutex> lk(g_devinfo_mu);
+  DevInfo& d = g_devinfo[device & 63];
+  if (!d.known) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return e;
+    d.known = true;
+    d.gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    d.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    strncpy(d.arch, prop.gcnArchName, sizeof d.arch - 1);
+  }
+  *out = d;
+  return hipSuccess;
+}
+
+std::vector<hipStream_t> g_streams[64];
+std::mutex g_streams_mu;
+
+hipError_t stream_acquire(int device, hipStream_t* out) {
+  {
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    auto& v = g_streams[device & 63];
+    if (!v.empty()) {
+      *out = v.back();
+      v.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void stream_release(int device, hipStream_t st) {   // the caller has synchronised it
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  auto& v = g_streams[device & 63];
+  if (v.size() < 64)
+    v.push_back(st);
+  else
+    hipStreamDestroy(st);
+}
 
 // ---- RCCL, loaded lazily so that single-GPU use has no dependency on it ---------------------
 struct Uid {
@@ -1304,7 +1435,7 @@ int small_prepare(nbmf_ctx* c) {
   const size_t pb_b = sizeof(double) * g_all * 2 * 16 * (size_t)c->KP, pl_b = sizeof(double) * g_all, pf_b = sizeof(unsigned long long) * g_all;
   const size_t total = 4 * fw + 4 * fh + sync_b + ll_b + pr_b + res_b + pb_b + pl_b + pf_b;
   char* base = nullptr;
-  HIPCHK(hipMalloc(&base, total));
+  HIPCHK(dmalloc(&base, total));
   HIPCHK(hipMemsetAsync(base, 0, total, c->stream));   // (pad strips of the second set of images are never written: they must read as zero)
   c->small.slab = base;
   char* p = base;
@@ -1406,7 +1537,7 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   }
   unsigned long long* dbg = nullptr;
   if (getenv("NBMF_SMALL_DEBUG")) {
-    HIPCHK(hipMalloc(&dbg, sizeof(unsigned long long) * 64 * 16));
+    HIPCHK(dmalloc(&dbg, sizeof(unsigned long long) * 64 * 16));
     HIPCHK(hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 64 * 16, c->stream));
     a.dbg = dbg;
   }
@@ -1417,7 +1548,7 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
     unsigned long long h[64 * 16];
     HIPCHK(hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(dbg);
+    dfree(dbg);
     double acc[8] = {0}, fine[7] = {0};
     int cnt = 0;
     for (int t = 8; t < 63 && t + 1 < max_iter; ++t) {
@@ -1483,9 +1614,9 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
 
 int ensure_losses(nbmf_ctx* c, int cap) {
   if (cap <= c->losses_cap) return NBMF_OK;
-  if (c->losses_d) HIPCHK(hipFree(c->losses_d));
+  if (c->losses_d) HIPCHK(dfree(c->losses_d));
   c->losses_d = nullptr;
-  HIPCHK(hipMalloc(&c->losses_d, sizeof(double) * (size_t)cap));
+  HIPCHK(dmalloc(&c->losses_d, sizeof(double) * (size_t)cap));
   c->losses_cap = cap;
   return NBMF_OK;
 }
@@ -1505,24 +1636,24 @@ int setup_workspaces(nbmf_ctx* c) {
   c->chunksW = (int)bW.size() - 1;
   c->bW_host = bW;
   for (int** p : {&c->cstartH, &c->cstartW}) {
-    if (*p) HIPCHK(hipFree(*p));
+    if (*p) HIPCHK(dfree(*p));
     *p = nullptr;
   }
-  HIPCHK(hipMalloc(&c->cstartH, sizeof(int) * bH.size()));
-  HIPCHK(hipMalloc(&c->cstartW, sizeof(int) * bW.size()));
+  HIPCHK(dmalloc(&c->cstartH, sizeof(int) * bH.size()));
+  HIPCHK(dmalloc(&c->cstartW, sizeof(int) * bW.size()));
   HIPCHK(hipMemcpy(c->cstartH, bH.data(), sizeof(int) * bH.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->cstartW, bW.data(), sizeof(int) * bW.size(), hipMemcpyHostToDevice));
   if (getenv("NBMF_DEBUG"))
     fprintf(stderr, "[nbmf] K_pad=%d path=%d: H-pass %d x %d workgroups (chunk %d blocks, %d slots), W-pass %d x %d (chunk %d, %d slots)\n",
             c->KP, c->data_kind, (int)(c->nA / 64), c->chunksH, c->CH_H, slotsH, (int)(c->mA / 64), c->chunksW, c->CH_W, slotsW);
   for (double** p : {&c->slabH, &c->slabW, &c->lossbuf}) {
-    if (*p) HIPCHK(hipFree(*p));
+    if (*p) HIPCHK(dfree(*p));
     *p = nullptr;
   }
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
-  HIPCHK(hipMalloc(&c->slabH, 2 * (size_t)c->chunksH * fh));
-  HIPCHK(hipMalloc(&c->slabW, (size_t)c->chunksW * fw));
-  HIPCHK(hipMalloc(&c->lossbuf, sizeof(double) * (size_t)c->chunksH * (c->nA / 16 / WG_WAVES)));
+  HIPCHK(dmalloc(&c->slabH, 2 * (size_t)c->chunksH * fh));
+  HIPCHK(dmalloc(&c->slabW, (size_t)c->chunksW * fw));
+  HIPCHK(dmalloc(&c->lossbuf, sizeof(double) * (size_t)c->chunksH * (c->nA / 16 / WG_WAVES)));
   return NBMF_OK;
 }
 
@@ -1616,13 +1747,12 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
                 e == hipSuccess ? "device count 0" : hipGetErrorString(e));
   if (device < 0 || device >= ndev) return fail(NBMF_ERR_ARG, "device %d out of range (have %d)", device, ndev);
   HIPCHK(hipSetDevice(device));
-  hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, device));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(NBMF_ERR_HIP, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  DevInfo info;
+  HIPCHK(device_info(device, &info));
+  if (!info.gfx950) return fail(NBMF_ERR_HIP, "device %d is %s; this library is built for gfx950 only", device, info.arch);
 
   nbmf_ctx* c = new nbmf_ctx();
-  c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->cus = info.cus;
   struct CtxGuard {   // a failure below releases what has been allocated so far
     nbmf_ctx* p;
     ~CtxGuard() {
@@ -1638,31 +1768,31 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
   c->KB = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8;
   c->KS = (k + SLICE_K - 1) / SLICE_K;
   c->KP = c->KS > 1 ? SLICE_K * c->KS : 16 * c->KB;
-  if (c->KS > 1) HIPCHK(hipMalloc(&c->theta, sizeof(double) * (size_t)c->mA * c->nA));
-  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (c->KS > 1) HIPCHK(dmalloc(&c->theta, sizeof(double) * (size_t)c->mA * c->nA));
+  HIPCHK(stream_acquire(device, &c->stream));
 
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
-  HIPCHK(hipMalloc(&c->Wn, fw));
-  HIPCHK(hipMalloc(&c->WT, fw));
-  HIPCHK(hipMalloc(&c->WG, fw));
-  HIPCHK(hipMalloc(&c->Hn, fh));
-  HIPCHK(hipMalloc(&c->HT, fh));
-  HIPCHK(hipMalloc(&c->HG, fh));
+  HIPCHK(dmalloc(&c->Wn, fw));
+  HIPCHK(dmalloc(&c->WT, fw));
+  HIPCHK(dmalloc(&c->WG, fw));
+  HIPCHK(dmalloc(&c->Hn, fh));
+  HIPCHK(dmalloc(&c->HT, fh));
+  HIPCHK(dmalloc(&c->HG, fh));
   // (the pass workspaces depend on the storage path: setup_workspaces, called by nbmf_upload)
-  HIPCHK(hipMalloc(&c->Pbuf, 2 * fh + 64));
+  HIPCHK(dmalloc(&c->Pbuf, 2 * fh + 64));
   c->n_prior_blocks = (int)(((size_t)c->KP * c->nA + 255) / 256);
-  HIPCHK(hipMalloc(&c->prior, sizeof(double) * 2 * (size_t)c->n_prior_blocks));
+  HIPCHK(dmalloc(&c->prior, sizeof(double) * 2 * (size_t)c->n_prior_blocks));
   c->prior_src = c->prior;
   c->n_prior_src = c->n_prior_blocks;
-  HIPCHK(hipMalloc(&c->scal, sizeof(double) * 8));
-  HIPCHK(hipMalloc(&c->sbuf, sizeof(double) * 8));
-  HIPCHK(hipMalloc(&c->flags, sizeof(int) * 8));
-  HIPCHK(hipMalloc(&c->stats, sizeof(unsigned long long) * 8));
-  HIPCHK(hipMalloc(&c->rowcnt, sizeof(double) * (size_t)c->mA));
+  HIPCHK(dmalloc(&c->scal, sizeof(double) * 8));
+  HIPCHK(dmalloc(&c->sbuf, sizeof(double) * 8));
+  HIPCHK(dmalloc(&c->flags, sizeof(int) * 8));
+  HIPCHK(dmalloc(&c->stats, sizeof(unsigned long long) * 8));
+  HIPCHK(dmalloc(&c->rowcnt, sizeof(double) * (size_t)c->mA));
   HIPCHK(hipMemset(c->flags, 0, sizeof(int) * 8));
   HIPCHK(hipMemset(c->scal, 0, sizeof(double) * 8));
   c->stage_bytes = (fw > fh ? fw : fh);
-  HIPCHK(hipMalloc(&c->stage, c->stage_bytes));
+  HIPCHK(dmalloc(&c->stage, c->stage_bytes));
   ctx_guard.p = nullptr;
   *out = c;
   return NBMF_OK;
@@ -1679,7 +1809,7 @@ int nbmf_destroy(nbmf_ctx* c) {
                   c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
                   c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta, c->small.slab};
   for (void* p : ptrs)
-    if (p) hipFree(p);
+    if (p) dfree(p);
   for (hipEvent_t e : c->ev) hipEventDestroy(e);
   for (hipEvent_t e : {c->evH, c->evF, c->ev1})
     if (e) hipEventDestroy(e);
@@ -1687,7 +1817,7 @@ int nbmf_destroy(nbmf_ctx* c) {
     hipStreamSynchronize(c->stream2);
     hipStreamDestroy(c->stream2);
   }
-  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->stream) stream_release(c->device, c->stream);   // (synchronised at the top of this function)
   delete c;
   return NBMF_OK;
 }
@@ -1745,14 +1875,14 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
     double*& a;
     void*& b;
     ~StagingGuard() {
-      if (a) hipFree(a);
-      if (b) hipFree(b);
+      if (a) dfree(a);
+      if (b) dfree(b);
     }
   } staging_guard{raw, rawm};
   const size_t msz = mask_kind == NBMF_MASK_F64 ? 8 : 1;
   const int64_t chunk_rows = std::min<int64_t>(round_up(U, PAD), chunk_rows_max);
-  HIPCHK(hipMalloc(&raw, (size_t)chunk_rows * V * 8));
-  if (mask) HIPCHK(hipMalloc(&rawm, (size_t)chunk_rows * V * msz));
+  HIPCHK(dmalloc(&raw, (size_t)chunk_rows * V * 8));
+  if (mask) HIPCHK(dmalloc(&rawm, (size_t)chunk_rows * V * msz));
 
   int rc = NBMF_OK;
   unsigned long long st[4] = {0, 0, 0, 0};
@@ -1765,18 +1895,18 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
     if (kind == DATA_F64M && mask_kind == NBMF_MASK_NONE) continue;
     const bool binary = kind == DATA_BIN;
     for (void** p : {&c->dataA, &c->dataB, &c->maskA, &c->maskB}) {
-      if (*p) hipFree(*p);
+      if (*p) dfree(*p);
       *p = nullptr;
     }
     c->data_kind = -1;
     const size_t esz = binary ? 1 : 8;
     const size_t bytes = tiles * 256 * esz;
-    HIPCHK(hipMalloc(&c->dataA, bytes));
-    HIPCHK(hipMalloc(&c->dataB, bytes));
+    HIPCHK(dmalloc(&c->dataA, bytes));
+    HIPCHK(dmalloc(&c->dataB, bytes));
     // (the pack kernel writes every tile of the padded mA x nA grid, pad entries included)
     if (kind == DATA_F64M) {
-      HIPCHK(hipMalloc(&c->maskA, bytes));
-      HIPCHK(hipMalloc(&c->maskB, bytes));
+      HIPCHK(dmalloc(&c->maskA, bytes));
+      HIPCHK(dmalloc(&c->maskB, bytes));
     }
     HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
 
@@ -1848,13 +1978,13 @@ int nbmf_generate(nbmf_ctx* c, uint64_t seed, double density, double observed) {
   if (is_sharded(c)) return fail(NBMF_ERR_STATE, "generate before attaching a communicator");
   if (int rc = set_device(c)) return rc;
   for (void** p : {&c->dataA, &c->dataB, &c->maskA, &c->maskB}) {
-    if (*p) hipFree(*p);
+    if (*p) dfree(*p);
     *p = nullptr;
   }
   c->data_kind = -1;
   const size_t tiles = (size_t)(c->mA / 16) * (c->nA / 16);
-  HIPCHK(hipMalloc(&c->dataA, tiles * 256));
-  HIPCHK(hipMalloc(&c->dataB, tiles * 256));
+  HIPCHK(dmalloc(&c->dataA, tiles * 256));
+  HIPCHK(dmalloc(&c->dataB, tiles * 256));
   HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
   dim3 grid((unsigned)(c->nA / 16 / 4), (unsigned)(c->mA / 16));
   if (grid.y > 65535u) return fail(NBMF_ERR_ARG, "nbmf_generate supports at most 1048560 internal rows");
@@ -1888,14 +2018,14 @@ int nbmf_upload_csr(nbmf_ctx* c, const int64_t* indptr, const int32_t* indices, 
   if (indptr[0] != 0 || indptr[U] != nnz) return fail(NBMF_ERR_ARG, "indptr does not span the %lld stored entries", (long long)nnz);
   if (masked && (mask_indptr[0] != 0 || mask_indptr[U] != mask_nnz)) return fail(NBMF_ERR_ARG, "mask indptr does not span its entries");
   for (void** p : {&c->dataA, &c->dataB, &c->maskA, &c->maskB}) {
-    if (*p) hipFree(*p);
+    if (*p) dfree(*p);
     *p = nullptr;
   }
   c->data_kind = -1;
   const long long RbA = c->mA / 16, RbB = c->nA / 16;
   const size_t tiles = (size_t)RbA * RbB;
-  HIPCHK(hipMalloc(&c->dataA, tiles * 256));
-  HIPCHK(hipMalloc(&c->dataB, tiles * 256));
+  HIPCHK(dmalloc(&c->dataA, tiles * 256));
+  HIPCHK(dmalloc(&c->dataB, tiles * 256));
   HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
   const long long dwords = (long long)tiles * 64;
   hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)c->dataA,
@@ -1906,13 +2036,13 @@ int nbmf_upload_csr(nbmf_ctx* c, const int64_t* indptr, const int32_t* indices, 
   struct DevBuf {
     void* p = nullptr;
     ~DevBuf() {
-      if (p) hipFree(p);
+      if (p) dfree(p);
     }
   } d_ptr, d_idx;
-  HIPCHK(hipMalloc(&d_ptr.p, sizeof(int64_t) * (size_t)(U + 1)));
+  HIPCHK(dmalloc(&d_ptr.p, sizeof(int64_t) * (size_t)(U + 1)));
   int64_t piece = 64ll << 20;
   if (const char* e = getenv("NBMF_CSR_PIECE")) piece = std::max<int64_t>(1, atoll(e));   // (tests: force several pieces)
-  HIPCHK(hipMalloc(&d_idx.p, sizeof(int32_t) * (size_t)std::max<int64_t>(1, std::min<int64_t>(piece, std::max(nnz, mask_nnz)))));
+  HIPCHK(dmalloc(&d_idx.p, sizeof(int32_t) * (size_t)std::max<int64_t>(1, std::min<int64_t>(piece, std::max(nnz, mask_nnz)))));
   for (int what = masked ? 0 : 1; what <= 1; ++what) {
     const int64_t* ip = what == 0 ? mask_indptr : indptr;
     const int32_t* ix = what == 0 ? mask_indices : indices;
@@ -2211,7 +2341,7 @@ static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
       c->psl_wp[p] = 16 * (b1 - b0);
     }
   }
-  if (shard_axis == 1 && !c->Qbuf) HIPCHK(hipMalloc(&c->Qbuf, sizeof(double) * (size_t)c->KP * c->mA));
+  if (shard_axis == 1 && !c->Qbuf) HIPCHK(dmalloc(&c->Qbuf, sizeof(double) * (size_t)c->KP * c->mA));
   // global observed count (the divisor of _solver.py:162) and, when the columns are split, the global
   // column count (the "/ n" of :54) and the per-row observed counts of the Duchi extension
   double h[2] = {c->n_obs, (double)c->n};
@@ -2461,14 +2591,14 @@ int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y) {
   if (!x || !y || n < 1 || op < 0 || op > 2) return fail(NBMF_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(device));
   double *d = nullptr, *o = nullptr;
-  HIPCHK(hipMalloc(&d, sizeof(double) * (size_t)n));
-  HIPCHK(hipMalloc(&o, sizeof(double) * (size_t)n));
+  HIPCHK(dmalloc(&d, sizeof(double) * (size_t)n));
+  HIPCHK(dmalloc(&o, sizeof(double) * (size_t)n));
   HIPCHK(hipMemcpy(d, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(unary_test_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, d, o, n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(y, o, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
-  hipFree(d);
-  hipFree(o);
+  dfree(d);
+  dfree(o);
   return NBMF_OK;
 }
 
