@@ -280,12 +280,7 @@ def main():
         if transport != "host" and not args.no_verify:
             transport, transport_check = verify_transport(ctx, group, reset, transport)
     elif args.force_comm:
-        if args.transport == "peer":
-            ctx.comm_init_peer(ctx.peer_export(0), 1, 0)
-            transport = "peer(1 rank)"
-        else:
-            ctx.comm_init(_hip.comm_unique_id(), 1, 0)
-            transport = "rccl(1 rank)"
+        transport = _dist.attach_comm(ctx, group, "rccl" if args.transport == "auto" else args.transport) + "(1 rank)"
 
     def sync():
         ctx.synchronize()                       # the library's own stream
@@ -351,7 +346,7 @@ def main():
                                "(_solver.py:54,57) timed in the same run on the same data",
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
                        "devices": devices,
-                       "transport_trials_s_per_5_iterations": trials, "transport_check": transport_check,
+                       "transport": transport, "transport_trials_s_per_5_iterations": trials, "transport_check": transport_check,
                        "sharding": (f"rows/{world} ({transport}: " + ("reduce-scatter of 2*K*N+1 doubles fused with the H-update, K*N back"
                                                              if transport.startswith("peer") else "all-reduce of 2*K*N+1 doubles"
                                                              + (" in two overlapped panels" if transport.endswith("2") else ""))
