@@ -1454,7 +1454,7 @@ int small_prepare(nbmf_ctx* c) {
   p += sync_b;
   c->small.ll_part = (double*)p;            // [parity][strip]
   p += ll_b;
-  c->small.prior_part = (double*)p;         // [iteration mod 3][strip][updating wave][2]
+  c->small.prior_part = (double*)p;         // [iteration mod 3][strip][updating wave] (sized for pairs: the second half is unused)
   p += pr_b;
   c->small.result = (int*)p;
   p += res_b;

@@ -6,9 +6,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from nbmf_mm_amd import _hip, _dist
-CASES = [("configs[0] 100x500 K=6", 100, 500, 6), ("animals 50x85 K=4", 50, 85, 4), ("paleo 253x902 K=8", 253, 902, 8),
-         ("lastfm 1226x285 K=8", 1226, 285, 8), ("lastfm 1226x285 K=16", 1226, 285, 16), ("1024x1024 K=16", 1024, 1024, 16),
-         ("1024x1024 K=32", 1024, 1024, 32), ("2000x2000 K=16", 2000, 2000, 16)]
+from bench_c1_loop_cases import CASES
 its = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 only = sys.argv[2] if len(sys.argv) > 2 else ""
 for name, m, n, k in [c for c in CASES if only in c[0]]:
