@@ -1544,9 +1544,24 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
     HIPCHK(hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 64 * 16, c->stream));
     a.dbg = dbg;
   }
+  unsigned long long* place = nullptr;
+  if (getenv("NBMF_SMALL_PLACEMENT")) {
+    HIPCHK(dmalloc(&place, sizeof(unsigned long long) * a.G));
+    a.place = place;
+  }
   void* params[] = {&a};
   SmallReservation cus_held(c->device, a.G, c->cus);   // until this function returns (it synchronises the stream first)
   HIPCHK(hipLaunchKernel(f, dim3(a.G), dim3(64 * NW), params, lds_bytes, c->stream));
+  if (place) {   // where the dispatcher put the workgroups: XCD . shader engine . CU
+    std::vector<unsigned long long> h(a.G);
+    HIPCHK(hipMemcpyAsync(h.data(), place, sizeof(unsigned long long) * a.G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dfree(place);
+    fprintf(stderr, "[nbmf] placement (xcd.se.cu):");
+    for (int i = 0; i < a.G; ++i)
+      fprintf(stderr, " %u.%u.%u", (unsigned)(h[i] >> 32) & 15u, (unsigned)(h[i] >> 13) & 7u, (unsigned)(h[i] >> 8) & 15u);
+    fprintf(stderr, "\n");
+  }
   if (dbg) {   // per-phase wall clock of workgroup 0 (10 ns ticks): tiles | update | barrier | tiles | update+loss | barrier
     unsigned long long h[64 * 16];
     HIPCHK(hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, c->stream));
