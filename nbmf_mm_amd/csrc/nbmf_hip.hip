@@ -185,6 +185,10 @@ __device__ __forceinline__ double log_tab(double x, const double2* tab) {
 // Per-lane selects on a 64-bit wave mask, written out because the pass kernels are VALU-issue bound next to
 // their MFMAs: a byte test is ONE SDWA compare (hipcc otherwise emits v_and + v_cmp), a double select is two
 // v_cndmask_b32 (with the zero / negated alternative folded into the operand).
+// CAUTION for callers: hipcc does not know that these statements are vector instructions, so it does not insert the
+// two wait states gfx950 needs between a vector write of a register and an MFMA that reads it.  A select's result
+// must therefore not be the operand of the very next MFMA: the pass kernel has the operand loads of the product
+// loop and a scheduling barrier in between, the single-launch kernel an explicit s_nop (see small_tile).
 typedef unsigned long long lanemask_t;
 __device__ __forceinline__ lanemask_t byte_set(uint32_t x, int byte) {   // lanes whose byte `byte` of x is non-zero
   lanemask_t m;
