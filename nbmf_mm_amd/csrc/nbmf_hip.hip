@@ -190,7 +190,21 @@ __device__ __forceinline__ double log_tab(double x, const double2* tab) {
 // must therefore not be the operand of the very next MFMA: the pass kernel has the operand loads of the product
 // loop and a scheduling barrier in between, the single-launch kernel an explicit s_nop (see small_tile).
 typedef unsigned long long lanemask_t;
-__device__ __forceinline__ lanemask_t byte_set(uint32_t x, int byte) {   // lanes whose byte `byte` of x is non-zero
+// The four byte tests of a code word in ONE statement: LLVM's hazard table for this chip asks for two wait states
+// between a vector instruction writing an SGPR pair and a vector instruction reading it; hipcc cannot see into the
+// assembly, and it does move a lone compare right in front of its select.  Kept together, the compares are followed
+// by the selects' own preparation (1 - Theta, ...), and tools/check_asm_mfma_hazard.py --sgpr verifies the distance
+// in every build (tests/test_isa_hazards.py).  (With an s_nop 1 inside the statement instead: -0.8 % on the bench.)
+__device__ __forceinline__ void byte_set4(uint32_t x, lanemask_t (&m)[4]) {
+  const uint32_t zero = 0u;
+  __asm__("v_cmp_ne_u32_sdwa %0, %4, %5 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+          "v_cmp_ne_u32_sdwa %1, %4, %5 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+          "v_cmp_ne_u32_sdwa %2, %4, %5 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+          "v_cmp_ne_u32_sdwa %3, %4, %5 src0_sel:BYTE_3 src1_sel:DWORD"
+          : "=&s"(m[0]), "=&s"(m[1]), "=&s"(m[2]), "=&s"(m[3])
+          : "v"(x), "v"(zero));
+}
+__device__ __forceinline__ lanemask_t byte_set(uint32_t x, int byte) {   // one of them (callers: keep it two instructions away from its select)
   lanemask_t m;
   const uint32_t zero = 0u;
   switch (byte) {

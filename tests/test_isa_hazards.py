@@ -19,6 +19,6 @@ def test_no_mfma_reads_a_fresh_inline_asm_result():
     build = subprocess.run(["make", "-C", os.path.join(ROOT, "nbmf_mm_amd", "csrc"), "asm"], capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-2000:]
     check = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_mfma_hazard.py"),
-                            os.path.join(ROOT, "build", "nbmf_hip.s")], capture_output=True, text=True)
+                            os.path.join(ROOT, "build", "nbmf_hip.s"), "--sgpr"], capture_output=True, text=True)
     assert check.returncode == 0, check.stdout[-3000:]
-    assert "MFMA instructions checked, 0 too close" in check.stdout
+    assert "MFMA instructions checked, 0 too close" in check.stdout and "; 0 vector reads" in check.stdout

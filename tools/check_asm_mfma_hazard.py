@@ -15,13 +15,22 @@ def regs(tok):
         else:
             out.add(int(m.group(3)))
     return out
-bad = total = 0
-kernel, in_asm, clock, last_asm_write = None, False, 0, {}
+sreg = re.compile(r"s\[(\d+):(\d+)\]|\bs(\d+)\b")
+def sregs(tok):
+    out = set()
+    for m in sreg.finditer(tok):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+bad = total = sbad = 0
+kernel, in_asm, clock, last_asm_write, last_asm_swrite = None, False, 0, {}, {}
 for line in open(path):
     s = line.strip()
     m = re.match(r"^(_Z\w+):", s)
     if m:
-        kernel, clock, last_asm_write = m.group(1), 0, {}
+        kernel, clock, last_asm_write, last_asm_swrite = m.group(1), 0, {}, {}
         continue
     if s.startswith(";;#ASMSTART"):
         in_asm = True; continue
@@ -44,6 +53,17 @@ for line in open(path):
                 bad += 1
                 print(f"{kernel}: {s}   <- v{r} written by inline asm {clock - last_asm_write[r] - 1} wait state(s) earlier")
                 break
+    if op.startswith("v_") and "--sgpr" in sys.argv:
+        # (LLVM's table for gfx940: a vector instruction reading an SGPR needs two wait states behind a vector write of it)
+        srcs = rest.split(",")[1:] if not op.startswith("v_cmp") else rest.split(",")[1:]
+        for r in set().union(*[sregs(t) for t in srcs]) if srcs else ():
+            if r in last_asm_swrite and clock - last_asm_swrite[r] - 1 < NEED:
+                sbad += 1
+                print(f"{kernel}: {s}   <- s{r} written by inline asm {clock - last_asm_swrite[r] - 1} wait state(s) earlier")
+                break
+    if in_asm and op.startswith("v_cmp"):
+        for r in sregs(rest.split(",")[0]):
+            last_asm_swrite[r] = clock
     if in_asm and op.startswith("v_") and not op.startswith("v_cmp"):
         dst = rest.split(",")[0]
         for r in regs(dst):
@@ -56,5 +76,5 @@ for line in open(path):
     if op.startswith(("s_cbranch", "s_branch", "s_barrier", "s_endpgm", "s_setpc")):
         pass   # (branches: the conservative view keeps the last writes; a taken branch only adds wait states)
     clock += 1
-print(f"{total} MFMA instructions checked, {bad} too close to an inline-assembly write")
+print(f"{total} MFMA instructions checked, {bad} too close to an inline-assembly write" + (f"; {sbad} vector reads of an SGPR too close to an inline-assembly compare" if "--sgpr" in sys.argv else ""))
 sys.exit(1 if bad else 0)
