@@ -1044,15 +1044,22 @@ PassArgs w_pass_args(nbmf_ctx* c) {
   return a;
 }
 
-int enqueue_w_update(nbmf_ctx* c, const double* q, int chunks, double n_div, int projection) {
+template <int GROUPS>
+int launch_w_update(nbmf_ctx* c, const double* q, int chunks, double n_div, int projection) {
   const size_t lds_bytes = sizeof(double) * ((size_t)c->KP + 2) * WU_COLS;
   if (lds_bytes > 65536)
-    HIPCHK(hipFuncSetAttribute((const void*)w_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(w_update_kernel, dim3((unsigned)(c->mA / WU_COLS)), dim3(WU_COLS * WU_GROUPS), lds_bytes, c->stream, q,
+    HIPCHK(hipFuncSetAttribute((const void*)w_update_kernel<GROUPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(w_update_kernel<GROUPS>, dim3((unsigned)(c->mA / WU_COLS)), dim3(WU_COLS * GROUPS), lds_bytes, c->stream, q,
                      chunks, c->Wn, c->WT, c->WG, c->k, c->KP, std::min(c->KP, SLICE_K), (long long)c->m, (long long)c->mA, n_div,
                      c->rowcnt, projection, c->flags);
   HIPCHK(hipGetLastError());
   return NBMF_OK;
+}
+int enqueue_w_update(nbmf_ctx* c, const double* q, int chunks, double n_div, int projection) {
+  // 1024-thread blocks up to two rounds of them (two are resident per CU), 256-thread blocks beyond (w_update_kernel;
+  // measured at K = 64: 32768 rows 28 against 30 us, 65536 rows 50 against 38 us)
+  return c->mA / WU_COLS <= 4LL * c->cus ? launch_w_update<32>(c, q, chunks, n_div, projection)
+                                        : launch_w_update<8>(c, q, chunks, n_div, projection);
 }
 
 // Rows of Y split: ordered sum of the H-pass slabs into [P1 | P2 | loglik] at `dst` (natural [KP][nA] twice);
