@@ -357,7 +357,10 @@ def main():
                          "peak_measured": PEAK_MEASURED_TFLOPS, "frac_of_measured": achieved / PEAK_MEASURED_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "bytes per launch (PMC: (2*FETCH_SIZE + WRITE_SIZE) KiB; algorithmic: "
-                                         "m*N code bytes + 2*chunks*K*N*8 slab bytes = %.3g)" % (m_loc * N + 2.0 * 16 * K * N * 8),
+                                         "m*N code bytes + 2*chunks*K*N*8 slab bytes = %.3g; with the factor reads every launch "
+                                         "also makes -- the stationary factor once per XCD and chunk pair, each chunk's two operand "
+                                         "images once: >= %.3g, DESIGN.md 4.1)"
+                                         % (m_loc * N + 2.0 * 16 * K * N * 8, m_loc * N + 2.0 * 16 * K * N * 8 + 8.0 * K * N * 8 + 2.0 * m_loc * K * 8),
                          "hpass_ms": h_ms, "wpass_ms": w_ms,
                          # the whole iteration against the same peak, two ways: EXECUTED MFMA flop (the W-pass runs one
                          # back-product instead of two, SURVEY N4: 6 + 4 = 10*m*N*K) -- the utilisation figure -- and the
