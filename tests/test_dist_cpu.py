@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU): the sharding arithmetic and the host-side plumbing of the multi-GPU
+"""world_size-2 (gloo and the product's own group) and world_size-8 tests (CPU): the sharding arithmetic and the host-side plumbing of the multi-GPU
 path.  The device work itself is covered by tests/test_gpu_dist.py on the GPU box."""
 import os
 import socket
@@ -52,14 +52,15 @@ def _worker(rank, world, port, q, kind):
         dist.close()
 
 
-@pytest.mark.parametrize("kind", ["gloo", "stdlib"])
-def test_sharded_iteration_equals_unsharded(kind):
+@pytest.mark.parametrize("kind,world", [("gloo", 2), ("stdlib", 2), ("stdlib", 8)])
+def test_sharded_iteration_equals_unsharded(kind, world):
+    """(8 ranks: the largest launch the benchmark driver makes, on the CPU)"""
     import multiprocessing as mp
     from oracle import nbmf_oracle as orc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kind)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
@@ -71,22 +72,27 @@ def test_sharded_iteration_equals_unsharded(kind):
     Y = (g.random((M, N)) < 0.3).astype(np.float64)
     mask = (g.random((M, N)) < 0.85).astype(np.float64)
     Wr, Hr, lr, _, _ = orc.solve(Y, K, max_iter=25, tol=0, alpha=1.2, beta=1.3, mask=mask, random_state=3)
-    assert [r[1:3] for r in res] == [(0, 150), (150, 301)]
+    from nbmf_mm_amd import _dist
+    assert [r[1:3] for r in res] == [_dist.shard_bounds(M, world, k) for k in range(world)]
+    if world == 2:
+        assert [r[1:3] for r in res] == [(0, 150), (150, 301)]
     W = np.concatenate([r[3] for r in res], axis=1).T
     np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-12)
     for r in res:
         np.testing.assert_allclose(r[4], Hr, rtol=0, atol=1e-12)       # H replicated and equal to the unsharded run
         np.testing.assert_allclose(r[5], lr, rtol=1e-12, atol=0)
         assert r[6] == bytes(range(128))
-    np.testing.assert_array_equal(res[0][4], res[1][4])                # bitwise identical across ranks
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][4], r[4])                 # bitwise identical across ranks
     # column split
-    assert [r[7][:2] for r in res] == [(0, 60), (60, 120)]
+    assert [r[7][:2] for r in res] == [_dist.shard_bounds(N, world, k) for k in range(world)]
     Hc = np.concatenate([r[7][3] for r in res], axis=1)
     np.testing.assert_allclose(Hc, Hr, rtol=0, atol=1e-12)
     for r in res:
         np.testing.assert_allclose(r[7][2].T, Wr, rtol=0, atol=1e-12)  # W replicated
         np.testing.assert_allclose(r[7][4], lr, rtol=1e-12, atol=0)
-    np.testing.assert_array_equal(res[0][7][2], res[1][7][2])
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][7][2], r[7][2])
 
 
 def test_shard_bounds_cover_and_balance():
@@ -307,8 +313,8 @@ def _worker_env(rank, world, port, q, tcp):
     q.put((rank, out))
 
 
-@pytest.mark.parametrize("tcp", [False, True])
-def test_stdlib_rendezvous_from_env(tcp):
+@pytest.mark.parametrize("tcp,world", [(False, 3), (True, 3), (False, 8)])
+def test_stdlib_rendezvous_from_env(tcp, world):
     """The product's own group as a launcher's environment describes it: abstract Unix socket named after
     MASTER_PORT (which the launcher itself may be listening on), or TCP with NBMF_RDZV_PORT."""
     import multiprocessing as mp
@@ -320,7 +326,6 @@ def test_stdlib_rendezvous_from_env(tcp):
         holder = socket.socket()
         holder.bind(("127.0.0.1", port))
         holder.listen(1)
-    world = 3
     procs = [ctx.Process(target=_worker_env, args=(r, world, port, q, tcp)) for r in range(world)]
     for p in procs:
         p.start()
@@ -332,10 +337,11 @@ def test_stdlib_rendezvous_from_env(tcp):
         holder.close()
     for r, o in enumerate(res):
         assert o["who"] == (r, world)
-        assert [d["rank"] for d in o["gather"]] == [0, 1, 2] and o["gather"][2]["blob"] == b"\x02" * 128
+        assert [d["rank"] for d in o["gather"]] == list(range(world)) and o["gather"][2]["blob"] == b"\x02" * 128
         np.testing.assert_array_equal(o["bcast"], np.arange(5))
-        assert o["sum"] == (6.0, 6.0)
-        assert o["agree"] == (True, False) and o["max"] == 3.5
+        total = world * (world + 1) / 2.0
+        assert o["sum"] == (total, total)
+        assert o["agree"] == (True, False) and o["max"] == 0.5 + world
         assert o["bits"] == res[0]["bits"]
 
 
