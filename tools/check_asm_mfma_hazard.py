@@ -2,10 +2,12 @@
 """gfx950: an MFMA must not read a VGPR within two wait states of a vector instruction writing it.  hipcc inserts the
 wait states for instructions it knows, but not behind INLINE ASSEMBLY (the hand-written selects of nbmf_hip.hip).  This
 walks build/nbmf_hip.s (`make -C nbmf_mm_amd/csrc asm`) and reports every MFMA whose A/B/C operand was written by an
-inline-assembly instruction fewer than NEED wait states earlier.  Exit status 1 if any."""
+inline-assembly instruction fewer than NEED wait states earlier; with --sgpr also every vector instruction that reads an
+SGPR fewer than NEED wait states behind an inline-assembly compare that wrote it.  Exit status 1 if any."""
 import re, sys
 NEED = 2
-path = sys.argv[1] if len(sys.argv) > 1 else "build/nbmf_hip.s"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+path = args[0] if args else "build/nbmf_hip.s"
 reg = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
 def regs(tok):
     out = set()
@@ -77,4 +79,4 @@ for line in open(path):
         pass   # (branches: the conservative view keeps the last writes; a taken branch only adds wait states)
     clock += 1
 print(f"{total} MFMA instructions checked, {bad} too close to an inline-assembly write" + (f"; {sbad} vector reads of an SGPR too close to an inline-assembly compare" if "--sgpr" in sys.argv else ""))
-sys.exit(1 if bad else 0)
+sys.exit(1 if bad or sbad else 0)
