@@ -347,3 +347,36 @@ def test_single_launch_hand_offs_are_reproducible(monkeypatch):
                     np.testing.assert_array_equal(a, b)
             assert ctx.small_stats() == (10, 0)
         np.testing.assert_allclose(l, lref, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("m,n,k,single", [
+    (4096, 300, 8, True),      # 256 row strips: one workgroup on every CU of the chip
+    (300, 2048, 12, True),     # 128 column strips: the most the loss-forming wave takes
+    (300, 2064, 12, False),    # 129 column strips: the five launches
+    (200, 300, 33, False),     # more than 32 components: the five launches
+])
+def test_single_launch_admission_edges(monkeypatch, m, n, k, single):
+    """At the edges of what the single-launch path admits (small_eligible): the problem either runs there or through
+    the five launches -- the statistics say which -- and both give the same curve and factors."""
+    from nbmf_mm_amd import _hip
+    r = np.random.default_rng(m + n + k)
+    Y = (r.random((m, n)) < 0.3).astype(np.float64)
+    mask = r.random((m, n)) < 0.9
+    W0 = r.uniform(0.1, 0.9, (k, m))
+    W0 /= W0.sum(axis=0, keepdims=True)
+    H0 = r.uniform(0.1, 0.9, (k, n))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NBMF_PERSISTENT", mode)
+        with _hip.Context(m, n, k) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            ctx.upload(Y, mask=mask)
+            ctx.set_factors(W0, H0)
+            losses, nit = ctx.run(30, 0.0)
+            out[mode] = (losses, nit) + ctx.get_factors() + (ctx.small_stats(),)
+    assert out["1"][4] == ((1, 0) if single else (0, 0)) and out["0"][4] == (0, 0)
+    assert out["1"][1] == out["0"][1] == 30
+    assert all(out["1"][0][i] <= out["1"][0][i - 1] + 1e-12 for i in range(1, 30))
+    np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out["1"][3], out["0"][3], rtol=0, atol=1e-12)
