@@ -61,6 +61,9 @@
 #ifndef NBMF_XCD_MAP
 #define NBMF_XCD_MAP 1   // give each XCD whole chunks of a sweep (see pass_kernel)
 #endif
+#ifndef NBMF_BATCH_RCP
+#define NBMF_BATCH_RCP 1   // binary path: the four reciprocals of a lane's entries from one (see pass_kernel)
+#endif
 #ifndef NBMF_NT_CODES
 #define NBMF_NT_CODES 1   // the once-read code stream is loaded non-temporally: fewer factor-panel lines evicted from L2 (c3 HBM traffic per launch H 0.994 -> 0.971, W 0.910 -> 0.843, L 0.718 -> 0.640 GB; same speed)
 #endif
