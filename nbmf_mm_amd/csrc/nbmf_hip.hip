@@ -61,6 +61,9 @@
 #ifndef NBMF_XCD_MAP
 #define NBMF_XCD_MAP 1   // give each XCD whole chunks of a sweep (see pass_kernel)
 #endif
+#ifndef NBMF_R2_BY_DIFFERENCE
+#define NBMF_R2_BY_DIFFERENCE 1   // H-mode: R2 = r - R1 (one add, exact: one of the two is zero) instead of a second select (two v_cndmask): H-pass -0.5 %
+#endif
 #ifndef NBMF_BATCH_RCP
 #define NBMF_BATCH_RCP 1   // binary path: the four reciprocals of a lane's entries from one (see pass_kernel)
 #endif
