@@ -189,11 +189,16 @@ int nbmf_device_synchronize(int device);
 
 /* Self-test hook used by the GPU tests: applies one of the pass kernel's scalar device routines to n
  * caller-supplied values (op 0: Newton reciprocal used on the binary path; op 1: the natural logarithm
- * of the general path; op 2: the general path's quotient, evaluated as (1 - 0.75 x) / x) so the host can
- * compare with IEEE 1/x, log(x) and the IEEE quotient (accuracy contracts: tests/test_gpu_parity.py). */
+ * of the general path; op 2: the general path's quotient, evaluated as (1 - 0.75 x) / x; ops 3, 4: the two quotients
+ * of an entry from one shared reciprocal, (1 - 0.75 x) / x and 0.75 x / ((1 - (x - 1e-8)) + 1e-8); op 5: 1/x by the
+ * binary path's shared reciprocal of four, groups of four consecutive values) so the host can compare with IEEE 1/x,
+ * log(x) and the IEEE quotients (accuracy contracts: tests/test_gpu_parity.py). */
 #define NBMF_SELFTEST_RCP 0
 #define NBMF_SELFTEST_LOG 1
 #define NBMF_SELFTEST_DIV 2
+#define NBMF_SELFTEST_DIV_PAIR_A 3
+#define NBMF_SELFTEST_DIV_PAIR_B 4
+#define NBMF_SELFTEST_RCP_OF_FOUR 5
 int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y);
 
 #ifdef __cplusplus

@@ -2637,7 +2637,7 @@ int nbmf_synchronize(nbmf_ctx* c) {
 }
 
 int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y) {
-  if (!x || !y || n < 1 || op < 0 || op > 2) return fail(NBMF_ERR_ARG, "bad argument");
+  if (!x || !y || n < 1 || op < 0 || op > 5) return fail(NBMF_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(device));
   double *d = nullptr, *o = nullptr;
   HIPCHK(dmalloc(&d, sizeof(double) * (size_t)n));

@@ -60,6 +60,23 @@ def test_quotient_accuracy(hip):
     assert hip.selftest_unary(2, np.array([4.0 / 3.0]))[0] == 0.0
 
 
+def test_shared_reciprocal_accuracy(hip):
+    """The product sweeps take several quotients from ONE reciprocal: the binary path the four reciprocals of
+    a lane's entries from that of their product, the general path the two quotients of an entry from the reciprocal
+    of the product of their denominators.  A few more roundings than a reciprocal of its own: within 3 ulp."""
+    r = np.random.default_rng(4)
+    d = np.concatenate([np.exp(r.uniform(np.log(1e-8), 0.0, 1 << 20)) + 1e-8, r.uniform(0.0, 1.0, 1 << 18) + 1e-8])
+    d = d[: len(d) // 4 * 4]
+    got = hip.selftest_unary(5, d)                      # groups of four consecutive arguments share a reciprocal
+    ulp = np.abs(got - 1.0 / d) / np.spacing(1.0 / d)
+    assert ulp.max() <= 3.0, ulp.max()
+    t2 = (1.0 - (d - 1e-8)) + 1e-8
+    for op, want in ((3, (1.0 - 0.75 * d) / d), (4, (0.75 * d) / t2)):
+        got = hip.selftest_unary(op, d)
+        ulp = np.abs(got - want) / np.maximum(np.spacing(np.abs(want)), 5e-324)
+        assert ulp.max() <= 3.0, (op, ulp.max())
+
+
 def test_log_accuracy(hip):
     # logarithm of the general path (256-entry table + series): absolute error <= 2.5e-16 + 1 ulp of the result on
     # (0, 2] -- the loss sums millions of such terms of size ~0.5 -- and the same special values as NumPy elsewhere
