@@ -218,21 +218,25 @@ def test_progress_reports_arrive_during_the_run(monkeypatch):
         np.testing.assert_array_equal(np.concatenate([v for _, v in calls]), losses)
 
 
-def test_eps_range_and_log_of_a_negative_number():
+def test_eps_range_and_log_of_a_negative_number(monkeypatch):
     """eps is a public argument (nbmf_mm_solver(eps=...)): far below the default the binary path's likelihood
-    product takes its per-entry form and still follows the oracle; a factor pair with Theta > 1 + eps gives the
-    reference's NaN loss (log of a negative number, _solver.py:150), also when an even number of entries are
-    negative; a denormal eps is refused."""
+    product and its shared reciprocal take their per-entry forms (below 1e-70; 1e-60 and 1e-69 are the last values
+    of the shared forms, where the product of four denominators is down to 1e-276) and still follow the oracle, by
+    either engine; a factor pair with Theta > 1 + eps gives the reference's NaN loss (log of a negative number,
+    _solver.py:150), also when an even number of entries are negative; a denormal eps is refused."""
     from nbmf_mm_amd import _hip, nbmf_mm_solver
     from oracle import nbmf_oracle as orc
     r = np.random.default_rng(4)
     Y = (r.random((90, 140)) < 0.3).astype(np.float64)
-    for eps in (1e-80, 1e-200):
-        W, H, l, _, _ = nbmf_mm_solver(Y, 5, max_iter=12, tol=0, random_state=1, eps=eps)
+    for eps in (1e-60, 1e-69, 1e-80, 1e-200):
         Wr, Hr, lr, _, _ = orc.solve(Y, 5, max_iter=12, tol=0, random_state=1, eps=eps)
-        np.testing.assert_allclose(l, lr, rtol=1e-10, atol=0)
-        np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-9)
-        np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-9)
+        for engine in ("1", "0"):
+            monkeypatch.setenv("NBMF_PERSISTENT", engine)
+            W, H, l, _, _ = nbmf_mm_solver(Y, 5, max_iter=12, tol=0, random_state=1, eps=eps)
+            np.testing.assert_allclose(l, lr, rtol=1e-10, atol=0)
+            np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-9)
+    monkeypatch.delenv("NBMF_PERSISTENT", raising=False)
     W0 = r.uniform(0.5, 0.9, (5, 90))                  # columns sum to ~3.5: Theta > 1 in many places
     H0 = r.uniform(0.5, 0.9, (5, 140))
     for Yc in (Y, r.random((90, 140))):                # binary path and general path
