@@ -158,11 +158,13 @@ def launch_ranks(n):
     has touched a GPU (it never does), wait for them, and pass on the worst exit code.  Rank 0's child prints
     the JSON line on the stdout it inherits."""
     from nbmf_mm_amd import _rendezvous
+    import secrets
     port = _rendezvous.free_port()
+    secret = os.environ.get("NBMF_RDZV_SECRET") or secrets.token_hex(16)    # only this job's ranks may join its rendezvous
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), NBMF_RDZV_SECRET=secret)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
@@ -214,6 +216,12 @@ def main():
                     help="attach a 1-rank communicator (RCCL, or the peer transport with --transport peer) even with --gpus 1: "
                          "the sharded code path and its per-iteration overhead, minus the wires")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal on a 1-GPU box)")
+    ap.add_argument("--storage", default="auto", choices=["auto", "f64", "f64w"],
+                    help="storage path of V on the device (nbmf_set_storage): auto = 1-byte tile codes for binary data; f64 = doubles, "
+                         "the arithmetic the reference applies to real-valued V (two quotients and two logarithms per entry); f64w = "
+                         "doubles plus float64 weight tiles (a real-valued mask)")
+    ap.add_argument("--no-f64-leg", action="store_true",
+                    help="skip the extra leg that times the same data on the 8-byte storage path (f64_storage on the line)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the untimed check of the chosen transport against the host transport (--gpus > 1)")
     args = ap.parse_args()
@@ -251,19 +259,23 @@ def main():
     proj = _hip.PROJ_DUCHI if args.projection == "duchi" else _hip.PROJ_NORMALIZE
     ctx.set_hyper(1.2, 1.2, 1e-8, proj)
     t_up = time.perf_counter()
+    X = Mk = None
     if args.device_data:
-        if world > 1:
-            raise SystemExit("--device-data is a single-GPU measurement option")
-        ctx.generate(args.seed, density=0.25, observed=0.9 if masked else 1.0)
+        # every rank generates its own rows of the same global matrix (nbmf_generate_slice)
+        ctx.generate(args.seed, density=0.25, observed=0.9 if masked else 1.0, row0=r0, col0=0, n_global=N)
         binary_path, bytes_up = True, 0
         args.no_cpu_baseline = True
     else:
         X, Mk = make_shard(M, N, r0, r1, args.seed, masked=masked)
         t_up = time.perf_counter()                     # the upload alone, not the synthetic generation before it
-        binary_path = ctx.upload(X, mask=Mk)
+        ctx.set_storage(args.storage)
+        binary_path = ctx.upload(X, mask=(Mk.astype(np.float64) if (masked and args.storage == "f64w") else Mk))
         bytes_up = X.nbytes + (Mk.nbytes if masked else 0)
-        del X, Mk
     t_up = time.perf_counter() - t_up
+    f64_leg = (world == 1 and args.storage == "auto" and binary_path and not args.device_data and not args.no_f64_leg
+               and not args.force_comm)
+    if not f64_leg:
+        X = Mk = None
 
     def reset():
         ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
@@ -319,6 +331,33 @@ def main():
         ctx.run(args.warmup, 0.0)
     dt_other, losses_other = timed(args.steps)
     ctx.close()
+    # the same data, factors and steps on the 8-byte storage path: what a real-valued V costs (the reference accepts any
+    # V in [0, 1], _base.py:90; BASELINE's configs say "fp64 V"): two quotients and two logarithms per entry instead of
+    # one reciprocal and no logarithm
+    f64 = None
+    if f64_leg:
+        ctx = _hip.Context(r1 - r0, N, K, device=dev_index)
+        ctx.set_hyper(1.2, 1.2, 1e-8, proj)
+        ctx.set_storage("f64")
+        ctx.upload(X, mask=Mk)
+        X = Mk = None
+        reset()
+        if args.warmup > 0:
+            ctx.run(args.warmup, 0.0)
+        ctx.timing_enable(not args.no_events)
+        dt64, losses64 = timed(args.steps)
+        t64 = ctx.timing()
+        ctx.close()
+        h64 = t64["hpass_ms"] / max(1, t64["hpass_launches"])
+        w64 = t64["wpass_ms"] / max(1, t64["wpass_launches"])
+        fl = 6.0 * (r1 - r0) * N * K
+        f64 = {"value": args.steps / dt64, "unit": "it/s", "storage": "f64 tiles, mask folded in as NaN (8 B per entry and image)",
+               "hpass_ms": h64, "wpass_ms": w64,
+               "frac": (fl / (h64 * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if h64 > 0 else None,
+               "wpass_executed_frac": (4.0 / 6.0 * fl / (w64 * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if w64 > 0 else None,
+               "executed_frac": (10.0 / 6.0 * fl * (args.steps / dt64) / 1e12) / PEAK_FP64_MFMA_TFLOPS,
+               "final_nll_per_entry": float(losses64[-1]),
+               "rel_nll_vs_u8_path": abs(float(losses64[-1]) - float(losses[-1])) / abs(float(losses[-1]))}
 
     if rank == 0:
         its = args.steps / dt
@@ -337,6 +376,7 @@ def main():
             "final_nll_per_entry": float(losses[-1]), "replicas_identical": replicas_identical,
             "loss_monotone": bool(all(losses[i] <= losses[i - 1] + 1e-12 for i in range(1, len(losses)))),
             "normalize_value": by_proj["normalize"], "duchi_value": by_proj["duchi"],
+            "f64_storage_value": f64["value"] if f64 else None, "f64_storage": f64,
             "final_nll_per_entry_" + other: float(losses_other[-1]),
             "config": {"workload": f"NBMF-MM fit, dense binary V {M}x{N} (float64 API, density 0.25), K={K}, "
                                    f"{'mask 90% observed' if masked else 'no mask'}, projection={args.projection}, "
@@ -344,7 +384,7 @@ def main():
                        "note": "projection=duchi is the README-only extension BASELINE configs[2] names (no reference code: "
                                "property-tested, parity unpinned); normalize_value is the reference's own path "
                                "(_solver.py:54,57) timed in the same run on the same data",
-                       "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else "f64 tiles",
+                       "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else ("f64 tiles + f64 weight tiles" if args.storage == "f64w" else "f64 tiles"),
                        "devices": devices,
                        "transport": transport, "transport_trials_s_per_5_iterations": trials, "transport_check": transport_check,
                        "sharding": (f"rows/{world} ({transport}: " + ("reduce-scatter of 2*K*N+1 doubles fused with the H-update, K*N back"

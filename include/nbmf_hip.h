@@ -90,6 +90,25 @@ int nbmf_upload_csr(nbmf_ctx* ctx, const int64_t* indptr, const int32_t* indices
  * host array would be impractical (BASELINE configs[4]: 360k x 17k = 49 GB). */
 int nbmf_generate(nbmf_ctx* ctx, uint64_t seed, double density, double observed);
 
+/* Generate this context's SLICE of a larger synthetic matrix: entry (i, j) of the context is entry (row0 + i,
+ * col0 + j) of a global matrix with n_global columns, i.e. the hash counter is (row0 + i) * n_global + (col0 + j).
+ * With row0 = col0 = 0 and n_global = n this is nbmf_generate.  For multi-GPU runs at sizes no host array can
+ * hold (BASELINE configs[3], 262144 x 8192 over 8 ranks): every rank generates the rows it owns of the SAME matrix
+ * a single context would generate whole, so sharded and unsharded runs can be compared entry for entry. */
+int nbmf_generate_slice(nbmf_ctx* ctx, uint64_t seed, double density, double observed, int64_t row0, int64_t col0,
+                        int64_t n_global);
+
+/* Storage path of the NEXT nbmf_upload.  NBMF_STORAGE_AUTO (default): the cheapest path the data allows -- byte
+ * codes for binary data with a binary (or no) mask, doubles otherwise.  NBMF_STORAGE_F64: never the
+ * byte codes, i.e. the arithmetic of the reference for real-valued V in [0, 1] (_base.py:90 accepts it; its tests
+ * feed np.random.rand) even when the values happen to be binary.  NBMF_STORAGE_F64_WEIGHTS: doubles plus a tile of
+ * float64 weights per data tile (the Y * mask of _solver.py:30-32 with a real-valued mask; all-ones without a mask).
+ * Measurement and test hook with no reference counterpart: results agree with the automatic path to rounding. */
+#define NBMF_STORAGE_AUTO 0
+#define NBMF_STORAGE_F64 1
+#define NBMF_STORAGE_F64_WEIGHTS 2
+int nbmf_set_storage(nbmf_ctx* ctx, int storage);
+
 /* Number of observed entries held by this context: Y.size or count_nonzero(mask), _solver.py:151,155. */
 int nbmf_get_n_obs(nbmf_ctx* ctx, double* n_obs);
 

@@ -23,6 +23,7 @@ NBMF_ERR_COMM = -5
 MASK_NONE, MASK_F64, MASK_U8 = 0, 1, 2
 PROJ_NORMALIZE, PROJ_DUCHI = 0, 1
 FLAG_BINARY_PATH = 1
+STORAGE = {"auto": 0, "f64": 1, "f64w": 2}
 MAX_K = 512
 PEER_HANDLE_BYTES = 128
 
@@ -33,7 +34,7 @@ SYMBOLS = [
     "nbmf_run", "nbmf_w_only_steps", "nbmf_loss", "nbmf_loglik", "nbmf_loglik_strict", "nbmf_comm_unique_id", "nbmf_comm_init",
     "nbmf_comm_init_host", "nbmf_peer_export", "nbmf_comm_init_peer", "nbmf_comm_detach",
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
-    "nbmf_set_progress", "nbmf_device_synchronize", "nbmf_small_stats",
+    "nbmf_set_progress", "nbmf_device_synchronize", "nbmf_small_stats", "nbmf_generate_slice", "nbmf_set_storage",
 ]
 
 
@@ -101,6 +102,8 @@ def load():
     lib.nbmf_set_hyper.argtypes = [c_void_p, c_double, c_double, c_double, c_int]
     lib.nbmf_upload.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, POINTER(c_int)]
     lib.nbmf_generate.argtypes = [c_void_p, ctypes.c_uint64, c_double, c_double]
+    lib.nbmf_generate_slice.argtypes = [c_void_p, ctypes.c_uint64, c_double, c_double, c_int64, c_int64, c_int64]
+    lib.nbmf_set_storage.argtypes = [c_void_p, c_int]
     lib.nbmf_get_n_obs.argtypes = [c_void_p, dp]
     lib.nbmf_set_factors.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.nbmf_get_factors.argtypes = [c_void_p, c_void_p, c_void_p]
@@ -225,10 +228,20 @@ class Context:
         self.binary_path = True
         return True
 
-    def generate(self, seed, density=0.25, observed=1.0):
-        """Fill the context with synthetic binary data generated on the device (see synthetic_reference)."""
-        _check(self._lib.nbmf_generate(self._h, int(seed), float(density), float(observed)))
+    def generate(self, seed, density=0.25, observed=1.0, row0=0, col0=0, n_global=None):
+        """Fill the context with synthetic binary data generated on the device (see synthetic_reference); with
+        ``row0`` / ``col0`` / ``n_global`` the context holds that slice of a larger matrix ``n_global`` columns wide
+        (every rank of a sharded run generates its own rows of the same global matrix)."""
+        _check(self._lib.nbmf_generate_slice(self._h, int(seed), float(density), float(observed), int(row0), int(col0),
+                                             int(self.n if n_global is None else n_global)))
         self.binary_path = True
+
+    def set_storage(self, storage="auto"):
+        """Hold the next :meth:`upload` to a storage path: "auto" (byte codes when the data allow), "f64" (doubles even
+        for binary values: the reference's arithmetic for real-valued V), "f64w" (doubles plus float64 weight tiles)."""
+        if storage not in STORAGE:
+            raise ValueError(f"storage must be one of {list(STORAGE)}")
+        _check(self._lib.nbmf_set_storage(self._h, STORAGE[storage]))
 
     def n_obs(self):
         v = c_double(0)

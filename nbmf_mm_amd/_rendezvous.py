@@ -12,12 +12,22 @@ hand): ``RANK``, ``WORLD_SIZE``, ``MASTER_ADDR``, ``MASTER_PORT``.
   * default: an abstract Unix socket named after MASTER_PORT -- single node, nothing to clean up, and it
     cannot collide with the launcher's own store, which holds the TCP port itself under PyTorch's launcher;
   * ``NBMF_RDZV_PORT=<port>``: TCP on MASTER_ADDR:<port> instead (ranks that do not share a kernel).
-Messages are pickled Python objects between processes of one job (the same trust domain as the launcher's).
+
+Who may join.  Nothing a peer sends is interpreted before the peer has proved that it belongs to the job:
+  * Unix socket: both ends read the other's credentials from the kernel (``SO_PEERCRED``) and require the same
+    user id -- an abstract socket has no file permissions and a guessable name, so another local user could
+    otherwise connect to the relay first, or bind the name first and play relay;
+  * a shared secret (``NBMF_RDZV_SECRET``, any string; ``bench.py``'s launcher draws a random one per job):
+    mutual challenge-response with HMAC-SHA256 over fresh nonces, fixed-size frames.  REQUIRED for TCP, optional
+    on top of the credential check for the Unix socket.
+Messages are a small tagged binary encoding of None / bool / int / float / str / bytes / list / tuple / dict /
+NumPy array -- decoding never executes anything (no pickle).
 """
 from __future__ import annotations
 
+import hmac
 import os
-import pickle
+import secrets
 import socket
 import struct
 import threading
@@ -25,9 +35,11 @@ import time
 
 import numpy as np
 
-__all__ = ["Group", "SingleGroup", "init_from_env", "free_port"]
+__all__ = ["Group", "SingleGroup", "init_from_env", "free_port", "encode", "decode"]
 
 _HDR = struct.Struct("<Q")
+_MAX_FRAME = 1 << 34          # 16 GiB: far above anything a job sends, far below a length field gone wrong
+_MAGIC = b"NBMFRDZ2"
 
 
 def free_port() -> int:
@@ -38,8 +50,129 @@ def free_port() -> int:
     return p
 
 
+# ---- wire format -----------------------------------------------------------------------------------------
+# one byte of tag, then: N none | T/F bool | i int64 | I big int (length-prefixed decimal) | d float64 |
+# s str / b bytes (u64 length + data) | l list / t tuple (u64 count + items) | m dict (u64 count + key, value
+# pairs) | a ndarray (dtype string, u8 ndim, u64 dims, raw C-order bytes; object dtypes are refused)
+def _enc(obj, out):
+    if obj is None:
+        out.append(b"N")
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b"T" if obj else b"F")
+    elif isinstance(obj, (int, np.integer)):
+        v = int(obj)
+        if -(1 << 63) <= v < (1 << 63):
+            out.append(b"i" + struct.pack("<q", v))
+        else:
+            s = str(v).encode()
+            out.append(b"I" + _HDR.pack(len(s)) + s)
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b"d" + struct.pack("<d", float(obj)))
+    elif isinstance(obj, str):
+        s = obj.encode("utf-8")
+        out.append(b"s" + _HDR.pack(len(s)) + s)
+    elif isinstance(obj, (bytes, bytearray, memoryview)):
+        s = bytes(obj)
+        out.append(b"b" + _HDR.pack(len(s)) + s)
+    elif isinstance(obj, (list, tuple)):
+        out.append((b"l" if isinstance(obj, list) else b"t") + _HDR.pack(len(obj)))
+        for x in obj:
+            _enc(x, out)
+    elif isinstance(obj, dict):
+        out.append(b"m" + _HDR.pack(len(obj)))
+        for k, v in obj.items():
+            _enc(k, out)
+            _enc(v, out)
+    elif isinstance(obj, np.ndarray):
+        if obj.dtype.hasobject:
+            raise TypeError("object arrays cannot cross the rendezvous")
+        dt = obj.dtype.str.encode()
+        out.append(b"a" + struct.pack("<B", len(dt)) + dt + struct.pack("<B", obj.ndim) +
+                   b"".join(_HDR.pack(d) for d in obj.shape))
+        out.append(np.ascontiguousarray(obj).tobytes())
+    else:
+        raise TypeError(f"cannot send {type(obj).__name__} through the rendezvous")
+
+
+def encode(obj) -> bytes:
+    out = []
+    _enc(obj, out)
+    return b"".join(out)
+
+
+def _dec(buf, pos):
+    tag = bytes(buf[pos:pos + 1])
+    pos += 1
+    if tag == b"N":
+        return None, pos
+    if tag == b"T":
+        return True, pos
+    if tag == b"F":
+        return False, pos
+    if tag == b"i":
+        return struct.unpack_from("<q", buf, pos)[0], pos + 8
+    if tag == b"d":
+        return struct.unpack_from("<d", buf, pos)[0], pos + 8
+    if tag in (b"I", b"s", b"b"):
+        (n,) = _HDR.unpack_from(buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError("truncated rendezvous message")
+        raw = bytes(buf[pos:pos + n])
+        pos += n
+        return (int(raw.decode()) if tag == b"I" else raw.decode("utf-8") if tag == b"s" else raw), pos
+    if tag in (b"l", b"t"):
+        (n,) = _HDR.unpack_from(buf, pos)
+        pos += 8
+        if n > len(buf) - pos:          # every item takes at least one byte
+            raise ValueError("truncated rendezvous message")
+        items = []
+        for _ in range(n):
+            x, pos = _dec(buf, pos)
+            items.append(x)
+        return (items if tag == b"l" else tuple(items)), pos
+    if tag == b"m":
+        (n,) = _HDR.unpack_from(buf, pos)
+        pos += 8
+        if 2 * n > len(buf) - pos:
+            raise ValueError("truncated rendezvous message")
+        d = {}
+        for _ in range(n):
+            k, pos = _dec(buf, pos)
+            v, pos = _dec(buf, pos)
+            d[k] = v
+        return d, pos
+    if tag == b"a":
+        ln = buf[pos]
+        pos += 1
+        dt = np.dtype(bytes(buf[pos:pos + ln]).decode())
+        pos += ln
+        if dt.hasobject:
+            raise ValueError("object arrays cannot cross the rendezvous")
+        nd = buf[pos]
+        pos += 1
+        shape = struct.unpack_from("<%dQ" % nd, buf, pos)
+        pos += 8 * nd
+        count = 1
+        for d in shape:
+            count *= d
+        nbytes = count * dt.itemsize
+        if nbytes > len(buf) - pos:
+            raise ValueError("truncated rendezvous message")
+        arr = np.frombuffer(buf, dtype=dt, count=count, offset=pos).reshape(shape).copy()
+        return arr, pos + nbytes
+    raise ValueError(f"unknown tag {tag!r} in rendezvous message")
+
+
+def decode(data):
+    obj, pos = _dec(memoryview(data) if not isinstance(data, memoryview) else data, 0)
+    if pos != len(data):
+        raise ValueError("trailing bytes in rendezvous message")
+    return obj
+
+
 def _send(sock, obj):
-    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    data = encode(obj)
     sock.sendall(_HDR.pack(len(data)) + data)
 
 
@@ -51,12 +184,45 @@ def _recv_exact(sock, n):
         if r == 0:
             raise ConnectionError("rendezvous peer closed the connection")
         got += r
-    return bytes(buf)
+    return buf
 
 
 def _recv(sock):
     (n,) = _HDR.unpack(_recv_exact(sock, _HDR.size))
-    return pickle.loads(_recv_exact(sock, n))
+    if n > _MAX_FRAME:
+        raise ConnectionError(f"rendezvous frame of {n} bytes refused")
+    return decode(_recv_exact(sock, n))
+
+
+# ---- admission ---------------------------------------------------------------------------------------------
+def _same_user(sock):
+    """Unix socket: the peer's user id as the kernel recorded it at connect()/listen() time."""
+    cred = sock.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i"))
+    _pid, uid, _gid = struct.unpack("3i", cred)
+    return uid == os.getuid()
+
+
+def _mac(key, role, n_cli, n_srv):
+    return hmac.new(key, role + n_cli + n_srv, "sha256").digest()
+
+
+def _handshake_client(sock, key):
+    n_cli = secrets.token_bytes(16)
+    sock.sendall(_MAGIC + n_cli)
+    reply = bytes(_recv_exact(sock, 16 + 32))
+    n_srv, tag = reply[:16], reply[16:]
+    if not hmac.compare_digest(tag, _mac(key, b"srv", n_cli, n_srv)):
+        raise ConnectionError("rendezvous listener failed authentication (NBMF_RDZV_SECRET differs, or it is not this job's relay)")
+    sock.sendall(_mac(key, b"cli", n_cli, n_srv))
+
+
+def _handshake_server(sock, key):
+    hello = bytes(_recv_exact(sock, len(_MAGIC) + 16))
+    if hello[:len(_MAGIC)] != _MAGIC:
+        return False
+    n_cli, n_srv = hello[len(_MAGIC):], secrets.token_bytes(16)
+    sock.sendall(n_srv + _mac(key, b"srv", n_cli, n_srv))
+    return hmac.compare_digest(bytes(_recv_exact(sock, 32)), _mac(key, b"cli", n_cli, n_srv))
 
 
 class SingleGroup:
@@ -85,18 +251,38 @@ class SingleGroup:
     def close(self):
         pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
 
 class Group:
     """``world`` ranks joined through rank 0's relay.  Every rank must make the same sequence of calls."""
 
-    def __init__(self, rank, world, address, timeout=300.0):
-        """address: ``("unix", name)`` (abstract socket) or ``("tcp", host, port)``."""
+    def __init__(self, rank, world, address, timeout=300.0, secret=None, collective_timeout=None):
+        """address: ``("unix", name)`` (abstract socket) or ``("tcp", host, port)``.
+        timeout: how long to wait for the listener / for all ranks to arrive / for a handshake step.
+        collective_timeout: bound on the wait inside a collective once the group stands (None = no bound: ranks that
+        do uneven amounts of work between collectives -- restarts, grid points -- may be minutes apart; a rank that
+        DIES is still noticed at once, its socket closes).
+        secret: bytes shared by the ranks of the job; default ``NBMF_RDZV_SECRET`` from the environment.  Required for TCP."""
         if world < 1 or not (0 <= rank < world):
             raise ValueError(f"bad rank {rank} / world {world}")
+        if secret is None and os.environ.get("NBMF_RDZV_SECRET"):
+            secret = os.environ["NBMF_RDZV_SECRET"].encode()
+        if address[0] == "tcp" and not secret:
+            raise ValueError("a TCP rendezvous needs a shared secret (NBMF_RDZV_SECRET, or secret=): anyone who can reach "
+                             "the port could otherwise join the job")
+        self._key = bytes(secret or b"")
+        self._unix = address[0] == "unix"
         self.rank, self.world, self._timeout = int(rank), int(world), float(timeout)
+        self._ctimeout = None if collective_timeout is None else float(collective_timeout)
         self._relay = None
         self._listener = None
         self._relay_error = None
+        self._sock = None
         if rank == 0:
             self._listener = self._listen(address)
             self._relay = threading.Thread(target=self._serve, name="nbmf-rendezvous", daemon=True)
@@ -106,6 +292,7 @@ class Group:
         ack = _recv(self._sock)
         if ack != ("welcome", self.world):
             raise ConnectionError(f"rendezvous handshake failed: {ack!r}")
+        self._sock.settimeout(self._ctimeout)
 
     # ---- sockets ------------------------------------------------------------------------------------
     @staticmethod
@@ -121,7 +308,7 @@ class Group:
         if address[0] == "tcp":
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         s.bind(self._target(address))
-        s.listen(self.world)
+        s.listen(self.world + 8)
         s.settimeout(self._timeout)
         return s
 
@@ -131,42 +318,96 @@ class Group:
             s = socket.socket(self._family(address), socket.SOCK_STREAM)
             try:
                 s.connect(self._target(address))
-                s.settimeout(self._timeout)
-                if address[0] == "tcp":
-                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                return s
             except (ConnectionRefusedError, FileNotFoundError, socket.timeout):
                 s.close()
                 if time.monotonic() > deadline:
                     raise ConnectionError(f"rank {self.rank}: no rendezvous listener at {address} after {self._timeout:.0f} s")
                 time.sleep(0.02)
+                continue
+            s.settimeout(self._timeout)
+            if address[0] == "tcp":
+                s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                s.setsockopt(socket.SOL_SOCKET, socket.SO_KEEPALIVE, 1)
+            elif not _same_user(s):
+                s.close()
+                raise ConnectionError(f"rank {self.rank}: the rendezvous listener at {address} belongs to another user")
+            _handshake_client(s, self._key)
+            return s
 
     # ---- rank 0's relay: one round = one message from every rank, answered with the list of all -------
+    def _admit(self, c):
+        """Authenticate a fresh connection and read its hello; returns the rank or None (connection closed)."""
+        try:
+            c.settimeout(min(self._timeout, 30.0))
+            if self._unix and not _same_user(c):
+                raise ConnectionError("peer of another user")
+            if not _handshake_server(c, self._key):
+                raise ConnectionError("authentication failed")
+            if not self._unix:
+                c.setsockopt(socket.SOL_SOCKET, socket.SO_KEEPALIVE, 1)
+            tag, r, w = _recv(c)
+            if tag != "hello" or w != self.world or not isinstance(r, int) or not (0 <= r < self.world):
+                _send(c, ("refused", f"unexpected hello {tag!r} rank {r} world {w}"))
+                raise ConnectionError("bad hello")
+            return r
+        except Exception:            # a stranger, a port scanner, a rank of another job: not this job's problem
+            try:
+                c.close()
+            except OSError:
+                pass
+            return None
+
     def _serve(self):
         conns = [None] * self.world
-        try:
-            while any(c is None for c in conns):
-                c, _ = self._listener.accept()
-                c.settimeout(self._timeout)
-                tag, r, w = _recv(c)
-                if tag != "hello" or w != self.world or not (0 <= r < self.world) or conns[r] is not None:
-                    _send(c, ("refused", f"unexpected hello {tag!r} rank {r} world {w}"))
+        lock = threading.Lock()
+
+        def admit(c):             # one thread per fresh connection: a silent stranger stalls nobody but itself
+            r = self._admit(c)
+            if r is None:
+                return
+            with lock:
+                taken = conns[r] is not None
+                if not taken:
+                    conns[r] = c
+            if taken:
+                try:
+                    _send(c, ("refused", f"rank {r} is already here"))
                     c.close()
+                except OSError:
+                    pass
+
+        try:
+            deadline = time.monotonic() + self._timeout
+            self._listener.settimeout(0.05)
+            while True:
+                with lock:
+                    if all(c is not None for c in conns):
+                        break
+                if time.monotonic() > deadline:
+                    raise ConnectionError(f"only {sum(c is not None for c in conns)} of {self.world} ranks arrived in {self._timeout:.0f} s")
+                try:
+                    c, _ = self._listener.accept()
+                except socket.timeout:
                     continue
-                conns[r] = c
+                threading.Thread(target=admit, args=(c,), daemon=True).start()
             for c in conns:
+                c.settimeout(self._ctimeout)
                 _send(c, ("welcome", self.world))
             while True:
-                msgs = []
+                frames = []
                 for c in conns:
-                    c.settimeout(None if not msgs else self._timeout)   # idle between collectives is not an error
-                    msgs.append(_recv(c))
-                if any(tag == "bye" for tag, _ in msgs):     # envelopes: ("msg", payload) or ("bye", None)
-                    break
-                data = pickle.dumps([payload for _, payload in msgs], protocol=pickle.HIGHEST_PROTOCOL)
-                frame = _HDR.pack(len(data)) + data
+                    (n,) = _HDR.unpack(_recv_exact(c, _HDR.size))
+                    if n > _MAX_FRAME:
+                        raise ConnectionError(f"frame of {n} bytes refused")
+                    frames.append(bytes(_recv_exact(c, n)))
+                # envelopes ("msg", payload) / ("bye", None): the relay looks at the tag only and passes the payload
+                # bytes on undecoded -- b"t" + count(2) + b"s" + len + tag ...
+                if any(not f.startswith(_MSG_PREFIX) for f in frames):
+                    break            # a ("bye", None) envelope (or anything that is not a message): the group ends
+                body = b"l" + _HDR.pack(len(frames)) + b"".join(f[_ENV_SKIP:] for f in frames)
+                out = _HDR.pack(len(body)) + body
                 for c in conns:
-                    c.sendall(frame)
+                    c.sendall(out)
         except Exception as e:       # a rank died or timed out: the others see their sockets close
             self._relay_error = e
         finally:
@@ -230,7 +471,12 @@ class Group:
         self.close()
 
 
-def init_from_env(timeout=300.0):
+# bytes of an encoded ("msg", payload) envelope in front of the payload: tuple tag + count, str tag + length + "msg"
+_MSG_PREFIX = encode(("msg", None))[:-1]
+_ENV_SKIP = len(_MSG_PREFIX)
+
+
+def init_from_env(timeout=300.0, collective_timeout=None):
     """The group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (see the module docstring)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -243,4 +489,4 @@ def init_from_env(timeout=300.0):
     else:
         # restarts by an elastic launcher get a fresh name: a relay of the previous attempt may still be closing
         address = ("unix", f"nbmf-rdzv-{port}-{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}")
-    return Group(rank, world, address, timeout=timeout)
+    return Group(rank, world, address, timeout=timeout, collective_timeout=collective_timeout)

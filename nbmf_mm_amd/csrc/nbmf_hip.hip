@@ -70,6 +70,21 @@
 #ifndef NBMF_NT_CODES
 #define NBMF_NT_CODES 1   // the once-read code stream is loaded non-temporally: fewer factor-panel lines evicted from L2 (c3 HBM traffic per launch H 0.994 -> 0.971, W 0.910 -> 0.843, L 0.718 -> 0.640 GB; same speed)
 #endif
+#ifndef NBMF_HAZARD_SEED
+#define NBMF_HAZARD_SEED 0   // 1 = compile a kernel with a deliberate MFMA-after-inline-assembly hazard (build self-test only)
+#endif
+#ifndef NBMF_ASM_SELECT
+#define NBMF_ASM_SELECT 0   // 1 = the selects of the binary path as inline assembly (round 2; needs tools/check_asm_mfma_hazard.py)
+#endif
+#ifndef NBMF_BYTE_SET8
+#define NBMF_BYTE_SET8 1   // W sweeps: all eight byte compares of a tile in one statement (hazard distance by construction); 0 = the observed-zero compares one by one, each a step ahead of its select
+#endif
+#ifndef NBMF_TWO_STRIPS
+#define NBMF_TWO_STRIPS 0   // 1 = K <= 32, binary path: a wave sweeps two adjacent column strips (see pass_ns).  Built, parity-green (all 105 GPU tests) and measured in round 3: NO gain (configs[1] H-pass 0.216 vs 0.214 ms, W-pass 0.159 vs 0.161 ms) -- what a tile costs besides its MFMAs is the ratio arithmetic itself, not the per-wave staging
+#endif
+#ifndef NBMF_TWO_STRIPS_WGS
+#define NBMF_TWO_STRIPS_WGS 2   // ... workgroups per CU those kernels are compiled for (register budget 512 / this per lane)
+#endif
 #ifndef NBMF_LDS_DMA
 #define NBMF_LDS_DMA 1   // stage the factor panels with global_load_lds (LDS-DMA); 0 = through registers
 #endif
@@ -210,6 +225,23 @@ __device__ __forceinline__ void byte_set4(uint32_t x, lanemask_t (&m)[4]) {
           : "=&s"(m[0]), "=&s"(m[1]), "=&s"(m[2]), "=&s"(m[3])
           : "v"(x), "v"(zero));
 }
+// The eight byte tests of a W-sweep tile (observed ones, then observed zeros) in ONE statement.  Distance by
+// construction: an observed-one mask is followed by at least the four observed-zero compares; an observed-zero mask
+// is first read by a select whose other operand is the reciprocal, which depends (through d = select(ym, ...) + eps) on
+// selects that come after this whole statement.
+__device__ __forceinline__ void byte_set8(uint32_t x, uint32_t y, lanemask_t (&m)[4], lanemask_t (&n)[4]) {
+  const uint32_t zero = 0u;
+  __asm__("v_cmp_ne_u32_sdwa %0, %8, %10 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+          "v_cmp_ne_u32_sdwa %1, %8, %10 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+          "v_cmp_ne_u32_sdwa %2, %8, %10 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+          "v_cmp_ne_u32_sdwa %3, %8, %10 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+          "v_cmp_ne_u32_sdwa %4, %9, %10 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+          "v_cmp_ne_u32_sdwa %5, %9, %10 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+          "v_cmp_ne_u32_sdwa %6, %9, %10 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+          "v_cmp_ne_u32_sdwa %7, %9, %10 src0_sel:BYTE_3 src1_sel:DWORD"
+          : "=&s"(m[0]), "=&s"(m[1]), "=&s"(m[2]), "=&s"(m[3]), "=&s"(n[0]), "=&s"(n[1]), "=&s"(n[2]), "=&s"(n[3])
+          : "v"(x), "v"(y), "v"(zero));
+}
 __device__ __forceinline__ lanemask_t byte_set(uint32_t x, int byte) {   // one of them (callers: keep it two instructions away from its select)
   lanemask_t m;
   const uint32_t zero = 0u;
@@ -221,6 +253,12 @@ __device__ __forceinline__ lanemask_t byte_set(uint32_t x, int byte) {   // one 
   }
   return m;
 }
+// Selects on such a mask: __builtin_amdgcn_inverse_ballot_w64 hands the SGPR pair to the compiler as a per-lane
+// condition, so the select is the compiler's own pair of v_cndmask_b32 (zero / negated alternatives folded in) --
+// and being instructions hipcc knows, it inserts the wait states an MFMA reading the result needs itself.  (Round 2
+// wrote them as inline assembly: a select two instructions in front of an MFMA then went unprotected, found as
+// run-to-run differences in the single-launch kernel.)
+#if NBMF_ASM_SELECT
 __device__ __forceinline__ double sel64(lanemask_t m, double a, double b) {   // m ? a : b
   const uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
   const uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
@@ -251,6 +289,12 @@ __device__ __forceinline__ double sel64_neg(lanemask_t m, double a, double b) { 
   __asm__("v_cndmask_b32_e64 %0, -%1, %2, %3" : "=v"(hi) : "v"(bhi), "v"(ahi), "s"(m));   // the float negate modifier flips bit 31
   return mk_double(lo, hi);
 }
+#else
+__device__ __forceinline__ double sel64(lanemask_t m, double a, double b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : b; }
+__device__ __forceinline__ double sel64_or0(lanemask_t m, double a) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : 0.0; }
+__device__ __forceinline__ double sel64_0or(lanemask_t m, double b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? 0.0 : b; }
+__device__ __forceinline__ double sel64_neg(lanemask_t m, double a, double b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : -b; }
+#endif
 
 __device__ __forceinline__ double wave_sum(double v) {
   // fixed butterfly order -> bitwise reproducible
@@ -279,6 +323,7 @@ struct nbmf_ctx {
   int KS = 1;               // slices of SLICE_K components (n_components > 128); KP = SLICE_K * KS then
   double* theta = nullptr;  // KS > 1: Theta in tile order, shared by the slices' sweeps
   int data_kind = -1;   // -1 = nothing uploaded
+  int storage = NBMF_STORAGE_AUTO;   // storage path the next nbmf_upload is held to (nbmf_set_storage)
   void *dataA = nullptr, *dataB = nullptr, *maskA = nullptr, *maskB = nullptr;
   double n_obs = 0, n_obs_global = 0;
   double* rowcnt = nullptr;
@@ -629,7 +674,7 @@ void arena_release(ArenaSlot* a) {
 // ---- pass launch ----------------------------------------------------------------------------
 template <int KB, int DATA, int MODE, int TH = 0>
 hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
-  dim3 grid(a.Cb / WG_WAVES, chunks);
+  dim3 grid(a.Cb / (WG_WAVES * pass_ns(KB, DATA)), chunks);
   constexpr int lds_bytes = ((NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES) + (DATA != DATA_BIN ? LOG_TABLE_BYTES : 0);
   if (lds_bytes > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -712,7 +757,7 @@ int resident_per_cu(int KB, int data_kind) {
 // Measured at c3 / K=64: 768 workgroups = exactly one round of the 768 resident slots is SLOWER (3.23 ms)
 // than 2048 (3.15 ms); anything from 1536 to 4608 is within 1 %.  `slots` is kept for diagnostics.
 // NBMF_TARGET_WGS=<n> overrides the target (tuning experiments only).
-void pick_chunks(int strips_groups, int Rb, int NB, int slots, int* chunks, int* CH) {
+void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int* chunks, int* CH) {
   (void)slots;
   int target = 2048;
   if (const char* e = getenv("NBMF_TARGET_WGS")) target = std::max(1, atoi(e));
@@ -724,7 +769,8 @@ void pick_chunks(int strips_groups, int Rb, int NB, int slots, int* chunks, int*
   //  sweep a single workgroup walks, not by per-workgroup overhead: 8-block chunks there.  BASELINE configs[0],
   //  100 x 500 with K = 6: 37.4 -> 26.2 us per iteration (26 700 -> 38 100 iterations/s); the 36-fit
   //  perplexity grid on the lastfm-sized matrix 0.63 -> 0.33 s.)
-  const int min_blocks = (long long)strips_groups * ((Rb + 63) / 64) >= 512 ? 64 : 8;
+  // (ns = strips per wave: a workgroup of the two-strip kernels does a 64-block sweep's work in 32 blocks)
+  const int min_blocks = (long long)strips_groups * ns * ((Rb + 63) / 64) >= 512 ? 64 / ns : 8;
   ch = std::max(ch, std::min(Rb, min_blocks));
   ch = (int)round_up(ch, NB);
   *CH = ch;
@@ -810,6 +856,9 @@ int all_reduce_inplace(nbmf_ctx* c, double* p, size_t count, hipStream_t st = nu
 
 inline bool is_sharded(const nbmf_ctx* c) { return c->comm || c->host_reduce || c->peer; }
 
+// column strips one workgroup of the pass kernels covers (4 waves x 1 or 2 strips per wave, see pass_ns)
+inline int wg_strips(const nbmf_ctx* c) { return WG_WAVES * pass_ns(c->KS > 1 ? 8 : c->KB, c->data_kind); }
+
 // Every sweep over image A takes in all entries of the padded mA x nA grid.  A pad entry has Theta == 0 and
 // counts as "not an observed one" (binary path: code 0; general path: y = 0, weight 0), so it contributes
 // exactly log(fl(fl(1-0)+eps)) = log(1+eps) to the likelihood; their total is removed before the loss is
@@ -827,7 +876,7 @@ double ll_pad_of(const nbmf_ctx* c, int strict = 0) {
 //   axis 0 (rows)     Theta-only sweep: the loglik scalar (the H-pass exchange is enqueue_iteration_rows)
 //   axis 1 (columns)  [loglik, prior A, prior B]: the products stay local, the scalars do not
 int enqueue_exchange_after_sweep(nbmf_ctx* c, const PassArgs& a, bool with_products, int strict) {
-  const int n_loss = c->chunksH * (a.Cb / WG_WAVES);   // one log-likelihood partial per workgroup
+  const int n_loss = c->chunksH * (a.Cb / wg_strips(c));   // one log-likelihood partial per workgroup
   const double pad = ll_pad_of(c, strict);
   if (!is_sharded(c)) {
     c->ll_ptr = nullptr;
@@ -870,7 +919,6 @@ int enqueue_theta(nbmf_ctx* c, int image) {
     a.C_alloc = image == 0 ? c->nA : c->mA;
     a.eps = c->eps;
     a.tiny_eps = c->eps < 1e-70;
-  a.tiny_eps = c->eps < 1e-70;
     HIPCHK(launch_theta(a, image == 0 ? c->chunksH : c->chunksW, c->stream));
   }
   return NBMF_OK;
@@ -986,7 +1034,7 @@ int enqueue_finalize(nbmf_ctx* c, int t, double tol, bool loglik_only = false, i
   // single GPU: per-wave partials + pad correction here; sharded: the exchanged scalar (pad already removed)
   const bool sh = is_sharded(c) && c->ll_ptr;
   const double* ll_src = sh ? c->ll_ptr : c->lossbuf;
-  const int n_ll = sh ? 1 : c->chunksH * (int)(c->nA / 16 / WG_WAVES);
+  const int n_ll = sh ? 1 : c->chunksH * (int)(c->nA / 16 / wg_strips(c));
   const double pad = sh ? 0.0 : ll_pad_of(c, strict);
   // axis 1: the prior sums were exchanged with the log-likelihood
   const bool prior_x = sh && c->shard_axis == 1;
@@ -1073,7 +1121,7 @@ int enqueue_w_update(nbmf_ctx* c, const double* q, int chunks, double n_div, int
 int enqueue_reduce_h_all(nbmf_ctx* c, double* dst, hipStream_t st) {
   const int KSK = std::min(c->KP, SLICE_K);
   const size_t per = (size_t)KSK * c->nA, tot = (size_t)c->KP * c->nA;
-  const int n_loss = c->chunksH * (int)(c->nA / 16 / WG_WAVES);
+  const int n_loss = c->chunksH * (int)(c->nA / 16 / wg_strips(c));
   for (int sl = 0; sl < c->KS; ++sl) {
     hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st,
                        (const double*)(c->slabH + (size_t)sl * c->chunksH * per),
@@ -1147,7 +1195,7 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   const long long offPR_prev = c->prior_src ? (long long)(c->prior_src - c->arena) : 0;
   const bool prev_in_arena = c->prior_src >= c->arena && c->prior_src < c->arena + c->arena_doubles;
   const int fin_t = (it > 0 && prev_in_arena) ? it - 1 : -1;
-  const int n_loss = c->chunksH * (a.Cb / WG_WAVES);
+  const int n_loss = c->chunksH * (a.Cb / wg_strips(c));
   // One column panel [pc0[p], pc0[p+1]) of the H-step on stream `st`: ordered slab sum into the arena, then the
   // fused reduce-scatter + Beta-MAP update + broadcast of this rank's slice of the panel (flag slot p).
   auto exchange_panel = [&](int p, hipStream_t st, unsigned long long e) -> int {
@@ -1266,7 +1314,7 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, s0));
   }
   if (two_streams) HIPCHK(hipEventRecord(c->evH, s0));
-  const int n_loss = c->chunksH * (a.Cb / WG_WAVES);
+  const int n_loss = c->chunksH * (a.Cb / wg_strips(c));
   auto reduce_panel = [&](int p, hipStream_t st) -> int {
     const long long c0 = c->pc0[p], wp = c->pc0[p + 1] - c0;
     double* d1 = c->Pbuf + c->pbase[p];
@@ -1677,8 +1725,9 @@ int setup_workspaces(nbmf_ctx* c) {
   const int NB = 8 / c->KB;
   const int slotsH = cus * resident_per_cu<MODE_H>(c->KB, c->data_kind);
   const int slotsW = cus * resident_per_cu<MODE_W>(c->KB, c->data_kind);
-  pick_chunks((int)(c->nA / 16 / WG_WAVES), (int)(c->mA / 16), NB, slotsH, &c->chunksH, &c->CH_H);
-  pick_chunks((int)(c->mA / 16 / WG_WAVES), (int)(c->nA / 16), NB, slotsW, &c->chunksW, &c->CH_W);
+  const int ns = wg_strips(c) / WG_WAVES;
+  pick_chunks((int)(c->nA / 16 / wg_strips(c)), (int)(c->mA / 16), NB, slotsH, ns, &c->chunksH, &c->CH_H);
+  pick_chunks((int)(c->mA / 16 / wg_strips(c)), (int)(c->nA / 16), NB, slotsW, ns, &c->chunksW, &c->CH_W);
   const std::vector<int> bH = chunk_boundaries((int)(c->mA / 16), c->CH_H);
   const std::vector<int> bW = chunk_boundaries((int)(c->nA / 16), c->CH_W);
   c->chunksH = (int)bH.size() - 1;
@@ -1896,7 +1945,7 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
 
   // cheap host-side guess of the storage path from a sample (the device pack verifies it exactly);
   // NBMF_FORCE_F64=1 keeps binary data on the 8-byte path (measurement only)
-  bool guess_bin = !(getenv("NBMF_FORCE_F64") && atoi(getenv("NBMF_FORCE_F64")) != 0);
+  bool guess_bin = c->storage == NBMF_STORAGE_AUTO && !(getenv("NBMF_FORCE_F64") && atoi(getenv("NBMF_FORCE_F64")) != 0);
   bool guess_mask_bin = true;   // a float64 mask holding only 0 and 1 is a binary mask
   {
     const int64_t rows = U < 8 ? U : 8;
@@ -1940,8 +1989,8 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   // exact counts say otherwise, and the next one is packed.
   for (int kind : {DATA_BIN, DATA_F64, DATA_F64M}) {
     if (kind == DATA_BIN && !guess_bin) continue;
-    if (kind == DATA_F64 && !guess_mask_bin) continue;
-    if (kind == DATA_F64M && mask_kind == NBMF_MASK_NONE) continue;
+    if (kind == DATA_F64 && (!guess_mask_bin || c->storage == NBMF_STORAGE_F64_WEIGHTS)) continue;
+    if (kind == DATA_F64M && mask_kind == NBMF_MASK_NONE && c->storage != NBMF_STORAGE_F64_WEIGHTS) continue;   // (no mask: all-ones weights)
     const bool binary = kind == DATA_BIN;
     for (void** p : {&c->dataA, &c->dataB, &c->maskA, &c->maskB}) {
       if (*p) dfree(*p);
@@ -2020,10 +2069,14 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   return NBMF_OK;
 }
 
-int nbmf_generate(nbmf_ctx* c, uint64_t seed, double density, double observed) {
+int nbmf_generate_slice(nbmf_ctx* c, uint64_t seed, double density, double observed, int64_t row0, int64_t col0,
+                        int64_t n_global) {
   if (!c) return fail(NBMF_ERR_ARG, "null context");
   if (!(density >= 0.0 && density <= 1.0) || !(observed >= 0.0 && observed <= 1.0))
     return fail(NBMF_ERR_ARG, "density and observed must lie in [0, 1]");
+  if (row0 < 0 || col0 < 0 || n_global < col0 + c->n)
+    return fail(NBMF_ERR_ARG, "slice [%lld.., %lld..+%lld) does not fit a matrix %lld columns wide", (long long)row0, (long long)col0,
+                (long long)c->n, (long long)n_global);
   if (is_sharded(c)) return fail(NBMF_ERR_STATE, "generate before attaching a communicator");
   if (int rc = set_device(c)) return rc;
   for (void** p : {&c->dataA, &c->dataB, &c->maskA, &c->maskB}) {
@@ -2035,11 +2088,12 @@ int nbmf_generate(nbmf_ctx* c, uint64_t seed, double density, double observed) {
   HIPCHK(dmalloc(&c->dataA, tiles * 256));
   HIPCHK(dmalloc(&c->dataB, tiles * 256));
   HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
-  dim3 grid((unsigned)(c->nA / 16 / 4), (unsigned)(c->mA / 16));
-  if (grid.y > 65535u) return fail(NBMF_ERR_ARG, "nbmf_generate supports at most 1048560 internal rows");
+  const long long RbA = c->mA / 16;
+  dim3 grid((unsigned)(c->nA / 16 / 4), (unsigned)std::min<long long>(RbA, 65535), (unsigned)((RbA + 65534) / 65535));
   hipLaunchKernelGGL(synth_kernel, grid, dim3(256), 0, c->stream, (uint32_t*)c->dataA, (uint32_t*)c->dataB,
-                     (long long)(c->mA / 16), (long long)(c->nA / 16), (long long)c->m, (long long)c->n,
-                     (unsigned long long)seed, density, observed, c->stats);
+                     RbA, (long long)(c->nA / 16), (long long)c->m, (long long)c->n,
+                     SynthSlice{(long long)row0, (long long)col0, (long long)n_global}, (unsigned long long)seed, density, observed,
+                     c->stats);
   HIPCHK(hipGetLastError());
   unsigned long long st[1] = {0};
   HIPCHK(hipMemcpyAsync(st, c->stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
@@ -2052,6 +2106,18 @@ int nbmf_generate(nbmf_ctx* c, uint64_t seed, double density, double observed) {
                      c->data_kind, (long long)(c->nA / 16), (long long)c->m, (long long)c->n, c->rowcnt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
+  return NBMF_OK;
+}
+
+int nbmf_generate(nbmf_ctx* c, uint64_t seed, double density, double observed) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  return nbmf_generate_slice(c, seed, density, observed, 0, 0, c->n);
+}
+
+int nbmf_set_storage(nbmf_ctx* c, int storage) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (storage < NBMF_STORAGE_AUTO || storage > NBMF_STORAGE_F64_WEIGHTS) return fail(NBMF_ERR_ARG, "unknown storage path %d", storage);
+  c->storage = storage;
   return NBMF_OK;
 }
 

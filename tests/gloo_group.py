@@ -46,4 +46,4 @@ def make_group(kind, rank, world, port):
     if kind == "gloo":
         return GlooGroup(rank, world, port)
     from nbmf_mm_amd import _rendezvous
-    return _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
+    return _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port), secret=b"tests-%d" % port)

@@ -2,6 +2,8 @@
 path.  The device work itself is covered by tests/test_gpu_dist.py on the GPU box."""
 import os
 import socket
+import time
+from struct import error as struct_error
 
 import numpy as np
 import pytest
@@ -294,8 +296,10 @@ def _worker_env(rank, world, port, q, tcp):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if tcp:
         os.environ["NBMF_RDZV_PORT"] = str(port)
+        os.environ["NBMF_RDZV_SECRET"] = "job-%d" % port       # TCP refuses to run without one
     else:
         os.environ.pop("NBMF_RDZV_PORT", None)
+        os.environ.pop("NBMF_RDZV_SECRET", None)               # the Unix socket checks the peer's user id instead
     from nbmf_mm_amd import _rendezvous
     with _rendezvous.init_from_env(timeout=60) as g:
         out = {"who": (g.rank, g.world)}
@@ -352,3 +356,117 @@ def test_single_group_is_the_identity():
     assert isinstance(g, _rendezvous.SingleGroup) and (g.rank, g.world) == (0, 1)
     a = np.array([1.0, 2.0])
     assert g.all_reduce(a) is a and g.all_gather(7) == [7] and g.broadcast("x") == "x" and g.agree(True) and g.max_float(2) == 2.0
+
+
+def test_rendezvous_wire_format_round_trip_and_refusals():
+    """Messages are a tagged binary encoding, not pickle: what the product sends survives, anything else is refused,
+    and a corrupted frame is an error rather than an action."""
+    from nbmf_mm_amd import _rendezvous as rz
+    msg = ("msg", {"rows": [{"K": 8, "alpha": 1.1, "loss": float("inf"), "name": "val"}], "w": np.arange(12.0).reshape(3, 4),
+                   "mask": np.array([True, False]), "h": b"\x00\x01" * 64, "big": 1 << 70, "neg": -5, "none": None, "t": (1, (2.5, "x")),
+                   "empty": np.zeros((0, 3), dtype=np.int32), "flag": np.bool_(True), "i32": np.int32(7), "f32": np.float32(0.5)})
+    back = rz.decode(rz.encode(msg))
+    assert back[0] == "msg" and back[1]["rows"] == msg[1]["rows"] and back[1]["big"] == 1 << 70 and back[1]["t"] == (1, (2.5, "x"))
+    np.testing.assert_array_equal(back[1]["w"], msg[1]["w"])
+    assert back[1]["w"].dtype == np.float64 and back[1]["mask"].dtype == np.bool_ and back[1]["empty"].shape == (0, 3)
+    assert back[1]["flag"] is True and back[1]["i32"] == 7 and back[1]["f32"] == 0.5 and back[1]["h"] == msg[1]["h"]
+    with pytest.raises(TypeError):
+        rz.encode(object())
+    with pytest.raises(TypeError):
+        rz.encode(np.array([object()], dtype=object))
+    data = rz.encode([1.0, "abc", np.arange(4)])
+    for bad in (data[:-3], data + b"N", b"l" + (1 << 60).to_bytes(8, "little") + b"N", b"Z", b"c" + data):
+        with pytest.raises((ValueError, struct_error)):
+            rz.decode(bad)
+
+
+def test_tcp_rendezvous_needs_a_secret():
+    from nbmf_mm_amd import _rendezvous as rz
+    old = os.environ.pop("NBMF_RDZV_SECRET", None)
+    try:
+        with pytest.raises(ValueError, match="secret"):
+            rz.Group(0, 2, ("tcp", "127.0.0.1", _free_port()))
+    finally:
+        if old is not None:
+            os.environ["NBMF_RDZV_SECRET"] = old
+
+
+def _worker_auth(rank, world, port, q, delay):
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from nbmf_mm_amd import _rendezvous as rz
+    time.sleep(delay if rank == 1 else 0.0)      # a late rank: the others wait inside the collective, however long
+    with rz.Group(rank, world, ("tcp", "127.0.0.1", port), timeout=60, secret=b"right") as g:
+        q.put((rank, g.all_gather(rank)))
+
+
+def test_strangers_cannot_join_and_late_ranks_can():
+    """Before the ranks arrive, somebody else talks to rank 0's relay: garbage, a well-formed handshake with the
+    wrong secret, a connection that says nothing.  None of it is parsed as a message, none of it takes a rank's
+    place, and the job completes -- with one rank arriving seconds late."""
+    import multiprocessing as mp
+    from nbmf_mm_amd import _rendezvous as rz
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_worker_auth, args=(r, world, port, q, 3.0)) for r in range(world)]
+    procs[0].start()
+    strangers = []
+    deadline = time.time() + 30
+    while True:                                   # wait for the listener
+        try:
+            s = socket.create_connection(("127.0.0.1", port), timeout=1)
+            break
+        except OSError:
+            assert time.time() < deadline
+            time.sleep(0.05)
+    s.sendall(b"\x80\x04\x95" + os.urandom(64))   # something pickle-shaped
+    strangers.append(s)
+    s = socket.create_connection(("127.0.0.1", port), timeout=5)
+    s.settimeout(5)
+    try:
+        rz._handshake_client(s, b"wrong")         # fails on the relay's side (our tag does not verify) or on ours
+        rz._send(s, ("hello", 1, world))
+    except (ConnectionError, OSError):
+        pass
+    strangers.append(s)
+    strangers.append(socket.create_connection(("127.0.0.1", port), timeout=5))   # silent
+    for p in procs[1:]:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for s in strangers:
+        s.close()
+    assert all(res[r] == [0, 1, 2] for r in range(world))
+
+
+def test_client_refuses_a_relay_that_does_not_know_the_secret():
+    """The other direction: somebody bound the address first and plays relay."""
+    import threading
+    from nbmf_mm_amd import _rendezvous as rz
+    port = _free_port()
+    srv = socket.socket()
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind(("127.0.0.1", port))
+    srv.listen(1)
+
+    def fake():
+        c, _ = srv.accept()
+        try:
+            rz._handshake_server(c, b"not the job's secret")
+            rz._send(c, ("welcome", 2))
+        except (ConnectionError, OSError):
+            pass
+        finally:
+            c.close()
+    t = threading.Thread(target=fake, daemon=True)
+    t.start()
+    with pytest.raises(ConnectionError, match="authentication"):
+        rz.Group(1, 2, ("tcp", "127.0.0.1", port), timeout=10, secret=b"right")
+    t.join(5)
+    srv.close()

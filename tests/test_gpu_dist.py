@@ -39,7 +39,7 @@ def _worker_dirbeta_restarts(rank, world, port, q):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     from nbmf_mm_amd import _dist, _rendezvous
-    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
+    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port), secret=b"tests-%d" % port)
     try:
         M, N, K, Y, mask = _problem()
         V, Vmask = Y[:300, :], mask[:300, :]                 # dir-beta on a 300 x 333 matrix, column shards
@@ -58,7 +58,7 @@ def _worker(rank, world, port, q):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     from nbmf_mm_amd import _dist, _rendezvous
-    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
+    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port), secret=b"tests-%d" % port)
     try:
         M, N, K, Y, mask = _problem()
         r0, r1 = _dist.shard_bounds(M, world, rank)
@@ -180,7 +180,7 @@ def _worker_axis1(rank, world, port, q):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     from nbmf_mm_amd import _dist, _rendezvous
-    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
+    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port), secret=b"tests-%d" % port)
     try:
         M, N, K, Y, mask = _problem()
         V, Vmask = Y[:300, :], mask[:300, :]
@@ -271,7 +271,7 @@ def _worker_wide(rank, world, port, q):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     from nbmf_mm_amd import _dist, _rendezvous
-    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
+    dist = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port), secret=b"tests-%d" % port)
     try:
         M, N, K, Y, mask = _wide_problem()
         r0, r1 = _dist.shard_bounds(M, world, rank)

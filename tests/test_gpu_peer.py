@@ -41,7 +41,7 @@ def _setup(rank, world, port):
     sys.path.insert(0, root)
     os.environ.setdefault("NBMF_PEER_TIMEOUT_MS", "20000")
     from nbmf_mm_amd import _rendezvous
-    return _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port))
+    return _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port), secret=b"tests-%d" % port)
 
 
 def _worker_rows(rank, world, port, q, transport="peer"):
