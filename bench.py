@@ -49,9 +49,9 @@ def make_shard(M, N, r0, r1, seed, density=0.25, observed=0.9, masked=True):
 
 def init_factors(M, N, K, seed):
     """Reference init rule (_solver.py:102-136): global RNG, W (M,K) then H (K,N), column-normalise W."""
-    np.random.seed(seed)
-    W0 = np.random.uniform(0.1, 0.9, (M, K))
-    H0 = np.random.uniform(0.1, 0.9, (K, N))
+    rs = np.random.RandomState(seed)          # the numbers of np.random.seed(seed) + global draws; private, so that
+    W0 = rs.uniform(0.1, 0.9, (M, K))        # several ranks in one process (one thread each) do not share a stream
+    H0 = rs.uniform(0.1, 0.9, (K, N))
     W = W0.T / W0.T.sum(axis=0, keepdims=True)
     return np.ascontiguousarray(W), H0
 
@@ -153,18 +153,24 @@ def verify_transport(ctx, group, reset, transport, iters=3):
     return used, f"{transport} DISAGREED with the host transport and was replaced by {used}"
 
 
-def launch_ranks(n):
-    """`bench.py --gpus N` invoked plainly: start N children of this script, one per GPU, BEFORE this process
-    has touched a GPU (it never does), wait for them, and pass on the worst exit code.  Rank 0's child prints
-    the JSON line on the stdout it inherits."""
+def launch_ranks(n, per_process=1):
+    """`bench.py --gpus N` invoked plainly: start the ranks as children of this script BEFORE this process has
+    touched a GPU (it never does), wait for them, and pass on the worst exit code.  One process per rank, or
+    (--ranks-per-process R) one process per R consecutive ranks, each rank a host thread with its own context and
+    stream: a rehearsal box admits only a few GPU processes at once.  Rank 0 prints the JSON line on the stdout it
+    inherits."""
     from nbmf_mm_amd import _rendezvous
     import secrets
     port = _rendezvous.free_port()
     secret = os.environ.get("NBMF_RDZV_SECRET") or secrets.token_hex(16)    # only this job's ranks may join its rendezvous
     procs = []
-    for r in range(n):
+    for r in range(0, n, per_process):
+        here = min(per_process, n - r)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), NBMF_RDZV_SECRET=secret)
+                   MASTER_PORT=str(port), NBMF_RDZV_SECRET=secret, NBMF_RANKS_IN_PROCESS=str(here))
+        if here > 1:
+            # the ranks of one process wait for each other INSIDE kernels: their streams must not share a hardware queue
+            env.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 4 * here)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
@@ -216,6 +222,10 @@ def main():
                     help="attach a 1-rank communicator (RCCL, or the peer transport with --transport peer) even with --gpus 1: "
                          "the sharded code path and its per-iteration overhead, minus the wires")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0 (rehearsal on a 1-GPU box)")
+    ap.add_argument("--ranks-per-process", type=int, default=1,
+                    help="with the built-in launcher: host this many consecutive ranks in each process, one thread, context and "
+                         "stream per rank (the peer transport then addresses same-process arenas directly); default one process "
+                         "per rank")
     ap.add_argument("--storage", default="auto", choices=["auto", "f64", "f64w"],
                     help="storage path of V on the device (nbmf_set_storage): auto = 1-byte tile codes for binary data; f64 = doubles, "
                          "the arithmetic the reference applies to real-valued V (two quotients and two logarithms per entry); f64w = "
@@ -229,15 +239,39 @@ def main():
     if args.overlap:
         os.environ["NBMF_OVERLAP"] = "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus))       # plain invocation: this process only starts the ranks
+        raise SystemExit(launch_ranks(args.gpus, max(1, args.ranks_per_process)))   # plain invocation: this process only starts the ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    here = int(os.environ.get("NBMF_RANKS_IN_PROCESS", "1"))
+    if here == 1:
+        return run_rank(args, rank, local_rank, world)
+    # several ranks in this process: one thread each; any failure ends the process (and with it the job)
+    import threading
+    import traceback
+    failed = []
 
+    def body(t):
+        try:
+            run_rank(args, rank + t, local_rank + t, world)
+        except BaseException:
+            traceback.print_exc()
+            failed.append(t)
+            os._exit(1)
+    threads = [threading.Thread(target=body, args=(t,)) for t in range(here)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if failed:
+        raise SystemExit(1)
+
+
+def run_rank(args, rank, local_rank, world):
     from nbmf_mm_amd import _dist, _hip, _rendezvous
-    group = _rendezvous.init_from_env()                 # plumbing only: handles / ids, barriers, max-over-ranks
+    group = _rendezvous.init_from_env(rank=rank, world=world)   # plumbing only: handles / ids, barriers, max-over-ranks
 
     M, N, K = (args.M * world if args.weak else args.M), args.N, args.K
     masked = not args.no_mask
@@ -285,7 +319,11 @@ def main():
     if world > 1:
         if args.transport == "auto":
             # time a few iterations over each transport that attaches and keep the faster one (setup, untimed)
-            transport, trials = _dist.attach_fastest(ctx, group, reset, candidates=("peer", "peer2", "rccl"))
+            # (RCCL refuses two ranks on one device -- and an attempt it refuses leaves its service threads behind, which
+            #  on a box with 16 host cores for 8 ranks slowed the timed run sevenfold: where ranks share a card, as in a
+            #  rehearsal on one GPU, it is not tried)
+            shared = len(set(group.all_gather(dev_index))) < world
+            transport, trials = _dist.attach_fastest(ctx, group, reset, candidates=("peer", "peer2") + (() if shared else ("rccl",)))
         else:
             transport = _dist.attach_comm(ctx, group, args.transport)
         transport_check = None
@@ -411,20 +449,22 @@ def main():
             "upload": {"seconds": t_up, "GBps_pcie_inclusive": (bytes_up / t_up / 1e9) if bytes_up else None},
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample_rows = 2048
-            cdt, threads, closs = cpu_baseline(N, K, args.seed, masked, args.projection, sample_rows, 3)
+            # the whole matrix needs >= 48 GiB of NumPy temporaries per iteration and ~90 s each; the
+            # prescribed sample is an 8192-row block (cost is linear in M at fixed N, K), 1 warm-up + 2 timed iterations
+            sample_rows, cpu_iters = min(8192, M), 2
+            cdt, threads, closs = cpu_baseline(N, K, args.seed, masked, args.projection, sample_rows, cpu_iters)
             out["cpu_baseline"] = {"value": 1.0 / (cdt * M / sample_rows), "unit": "it/s", "cores": threads,
                                    "kind": "port",
-                                   "sample": f"oracle/nbmf_oracle.py (NumPy+OpenBLAS) on the first {sample_rows} rows x {N} cols, "
-                                             f"3 iterations after 1 warm-up = {cdt:.2f} s/it, scaled x{M // sample_rows} to {M} rows "
-                                             f"(cost is linear in M)",
+                                   "sample": f"oracle/nbmf_oracle.py (NumPy+OpenBLAS) on the first {sample_rows} rows x {N} cols (SURVEY 8d's "
+                                             f"row block), {cpu_iters} iterations after 1 warm-up = {cdt:.2f} s/it, scaled x{M / sample_rows:g} to "
+                                             f"{M} rows (cost is linear in M)",
                                    "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
                                    "host_ram_gb": host_ram_gb()}
             out["speedup_vs_cpu"] = its / out["cpu_baseline"]["value"]
             # parity number on the line: the HIP path on that same sample against the oracle
-            hloss = hip_sample_loss(N, K, args.seed, masked, args.projection, dev_index, sample_rows, 3)
+            hloss = hip_sample_loss(N, K, args.seed, masked, args.projection, dev_index, sample_rows, cpu_iters)
             out["parity"] = {"rel_nll_vs_oracle": abs(hloss - closs) / abs(closs), "hip_nll": hloss, "oracle_nll": closs,
-                             "sample": f"first {sample_rows} rows, same init, 4 iterations, projection={args.projection}",
+                             "sample": f"first {sample_rows} rows, same init, {1 + cpu_iters} iterations, projection={args.projection}",
                              "tolerance": 1e-8}
         print(json.dumps(out), flush=True)
     group.close()

@@ -122,6 +122,22 @@ int nbmf_get_factors(nbmf_ctx* ctx, double* W_kxm, double* H_kxn);
  * *n_iter receives iteration+1 (:215).  Factors stay on the device (nbmf_get_factors). */
 int nbmf_run(nbmf_ctx* ctx, int max_iter, double tol, double* losses, int* n_iter);
 
+/* n_problems INDEPENDENT fits of the data this context holds, each with its own Beta prior (alpha[p], beta[p]) and its
+ * own initial factors (W0: n_problems x k x m, H0: n_problems x k x n, internal layout as nbmf_set_factors), the
+ * other hyper-parameters (eps, projection) as set: the loops of the reference's experiment driver -- the 36-point
+ * (alpha, beta) grids and the K sweeps of examples/reproduce_magron2022.py:75-340 over train_nbmf_mm (:49-73) -- and
+ * the n_init restarts of README.md:144.  Outputs per problem: losses (row p of an n_problems x max_iter array, the
+ * first n_iter[p] entries), n_iter[p], final factors (W_out, H_out, shaped like the inputs).
+ * Small problems (the reference's datasets: 50 x 85 ... 1226 x 285) run as many at a time as the chip holds, in ONE
+ * persistent launch per group -- each fit keeps its CUs, its own barrier words and stops on its own; larger ones run
+ * one after the other.  Either way problem p's results are bit for bit those of nbmf_set_hyper(alpha[p], beta[p]) +
+ * nbmf_set_factors + nbmf_run + nbmf_get_factors.  The context's own factors are left as they were when the
+ * single-launch path served the batch, and hold the last problem's otherwise. */
+int nbmf_run_batch(nbmf_ctx* ctx, int n_problems, const double* alpha, const double* beta, const double* W0, const double* H0,
+                   int max_iter, double tol, double* losses, int* n_iter, double* W_out, double* H_out);
+/* Diagnostics: persistent launches nbmf_run_batch made on this context and the problems they served. */
+int nbmf_batch_stats(nbmf_ctx* ctx, int* launches, int* problems);
+
 /* Progress reports while nbmf_run works (the `verbose` prints of _solver.py:165-166 need the losses as they
  * arrive, not after the run): with a callback set, nbmf_run synchronises after every `every` iterations and
  * hands over the losses that have become final since the last report -- iterations [first, first+count),
@@ -187,11 +203,25 @@ int nbmf_comm_init_host(nbmf_ctx* ctx, nbmf_host_allreduce_fn fn, void* user, in
  *   3. every rank: nbmf_comm_init_peer(ctx, all_handles, nranks, rank, shard_axis)
  *      (maps the arenas, runs a known-answer exchange, reduces the global counts; on failure the context is
  *       left unattached so the caller can fall back to nbmf_comm_init)
- * One process per rank (HIP IPC does not map a handle inside the process that exported it); at most 16
- * ranks.  No reference counterpart. */
-#define NBMF_PEER_HANDLE_BYTES 128
+ * One process per rank, or several ranks (contexts, one host thread each) in one process: a handle block also
+ * names the exporting process and the arena's address there, and a rank of the same process uses the memory
+ * directly (HIP IPC does not map a handle inside the process that exported it; across devices of one process peer
+ * access is enabled instead).  At most 16 ranks.  No reference counterpart. */
+#define NBMF_PEER_HANDLE_BYTES 192
 int nbmf_peer_export(nbmf_ctx* ctx, int shard_axis, void* handle);
 int nbmf_comm_init_peer(nbmf_ctx* ctx, const void* handles, int nranks, int rank, int shard_axis);
+
+/* Row split (shard_axis 0) only: cut the per-iteration exchange into `panels` column panels (1 or 2).  With 2, the
+ * second panel's exchange travels on a side stream while the first panel's H-update is applied and the W-pass
+ * starts on the chunks that read only those columns.  0 = the default (1 panel, or 2 if the
+ * environment says NBMF_OVERLAP=1).  Takes effect at the next nbmf_comm_init*; every rank must choose the same. */
+int nbmf_set_exchange_panels(nbmf_ctx* ctx, int panels);
+
+/* Bound on every wait of the peer transport attached NEXT (milliseconds; 0 = the default: NBMF_PEER_TIMEOUT_MS from
+ * the environment, else 30000).  A caller that is only probing a transport (bench.py times each candidate over a few
+ * iterations before the run) sets a short bound for the probe and the default for the run, so that a transport which
+ * cannot work on this machine costs seconds, not a timeout per exchange. */
+int nbmf_set_peer_timeout_ms(nbmf_ctx* ctx, double ms);
 
 /* Drop the attached communicator (RCCL, host or peer): the context is a single-GPU context over its own
  * shard again and another nbmf_comm_init* may follow.  Collective in effect: every rank must do the same. */

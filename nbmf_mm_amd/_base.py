@@ -6,7 +6,7 @@ import numpy as np
 from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array
 
-from ._solver import device_score, nbmf_mm_solver, w_only_transform
+from ._solver import device_score, nbmf_mm_restarts, nbmf_mm_solver, w_only_transform
 from ._utils import check_is_fitted
 
 # Accepted spellings of the two orientations: the exact strings of src/nbmf_mm/_base.py:127-137
@@ -97,7 +97,15 @@ class NBMFMM(BaseEstimator, TransformerMixin):
         n_init = int(self.n_init)
         if n_init < 1:
             raise ValueError("n_init must be >= 1")
-        best = None
+        if n_init > 1 and not self.verbose:
+            # restarts share one upload and one library call; small problems run several at a time in one launch
+            best, _ = nbmf_mm_restarts(
+                X, self.n_components, n_init, max_iter=self.max_iter, tol=self.tol, alpha=self.alpha, beta=self.beta,
+                W_init=self.W_init, H_init=self.H_init, mask=mask, random_state=self.random_state, orientation=orientation,
+                projection=self._projection(), device=self.device)
+            n_init = 0
+        else:
+            best = None
         for r in range(n_init):
             seed = self.random_state
             if r > 0 and seed is not None:

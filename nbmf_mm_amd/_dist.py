@@ -35,12 +35,13 @@ def global_init(M, N, K, random_state, W_init=None, H_init=None):
     """The reference's init (src/nbmf_mm/_solver.py:102-136) evaluated identically on every rank:
     seed the global RNG, draw W (M,K) then H (K,N) unless given, column-normalise W.
     Returns W (K,M) and H (K,N)."""
-    if random_state is not None:
-        np.random.seed(random_state)
+    # (a private legacy generator seeded like np.random.seed(random_state) gives the same numbers as the global
+    #  draw and is safe when several ranks live in one process, one thread each; without a seed the global one is used)
+    rs = np.random.RandomState(random_state) if random_state is not None else np.random
     if W_init is None:
-        W_init = np.random.uniform(0.1, 0.9, (M, K))
+        W_init = rs.uniform(0.1, 0.9, (M, K))
     if H_init is None:
-        H_init = np.random.uniform(0.1, 0.9, (K, N))
+        H_init = rs.uniform(0.1, 0.9, (K, N))
     W = np.asarray(W_init, dtype=np.float64).T
     W = W / W.sum(axis=0, keepdims=True)
     return np.ascontiguousarray(W), np.ascontiguousarray(H_init, dtype=np.float64)
@@ -110,17 +111,13 @@ def attach_comm(ctx, group, transport="auto", shard_axis=0):
         return host()
     if transport in ("rccl2", "peer2"):
         # the same transport with the exchange cut into two column panels, the second one travelling while the first
-        # is applied and the W-pass starts on its columns (NBMF_OVERLAP; rows split only)
-        import os
-        old = os.environ.get("NBMF_OVERLAP")
-        os.environ["NBMF_OVERLAP"] = "1"
+        # is applied and the W-pass starts on its columns (rows split only).  A per-context setting, not an environment
+        # variable: several ranks may live in one process.
+        ctx.set_exchange_panels(2)
         try:
             attach_comm(ctx, group, transport[:-1], shard_axis)
         finally:
-            if old is None:
-                del os.environ["NBMF_OVERLAP"]
-            else:
-                os.environ["NBMF_OVERLAP"] = old
+            ctx.set_exchange_panels(0)
         return transport
     if transport not in ("peer", "rccl", "auto"):
         raise ValueError(f"unknown transport {transport!r}")
@@ -136,20 +133,31 @@ def attach_comm(ctx, group, transport="auto", shard_axis=0):
     return host()
 
 
-def attach_fastest(ctx, group, reset, shard_axis=0, candidates=("peer", "rccl"), iters=5):
+def attach_fastest(ctx, group, reset, shard_axis=0, candidates=("peer", "rccl"), iters=5, probe_timeout_ms=5000.0):
     """Attach whichever of ``candidates`` runs the iteration fastest on THIS machine: each one that attaches on
     every rank is timed over ``iters`` iterations (max over ranks) and detached again; the winner is attached
     for good (the host transport if none attaches).  ``reset()`` must restore the factors (``ctx.set_factors``)
     -- it is called before every trial and once more at the end.  Returns ``(transport, {name: seconds})``.
     ("peer2" and "rccl2" may be added to ``candidates``: the two-panel forms win once the exchange itself takes
-    longer than about 70 us, which only a machine with real links can tell.)"""
+    longer than about 70 us, which only a machine with real links can tell.)
+    While probing, the peer transport's waits are bounded by ``probe_timeout_ms`` instead of the 30 s of a run: a
+    transport that attaches but cannot exchange on this machine costs one short timeout, and a family ("peer" and
+    "peer2" are the same kernels) that has failed once is not tried again -- the worst case of the whole selection is
+    about two probe timeouts plus the RCCL set-up, not minutes."""
     import time
-    timings = {}
+    timings, failed_family = {}, set()
     for name in candidates:
+        family = name.rstrip("2")
+        if family in failed_family:
+            continue
+        ctx.set_peer_timeout_ms(probe_timeout_ms)
         try:
             attach_comm(ctx, group, name, shard_axis)
         except _REFUSED:
+            failed_family.add(family)
             continue                                  # refused on some rank: every rank got the same answer
+        finally:
+            ctx.set_peer_timeout_ms(0.0)
         try:
             reset()
             ctx.run(2, 0.0)
@@ -166,6 +174,8 @@ def attach_fastest(ctx, group, reset, shard_axis=0, candidates=("peer", "rccl"),
         ctx.comm_detach()
         if ok:
             timings[name] = t
+        else:
+            failed_family.add(family)
     if timings:
         best = min(timings, key=timings.get)
         attach_comm(ctx, group, best, shard_axis)

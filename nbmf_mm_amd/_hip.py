@@ -25,7 +25,7 @@ PROJ_NORMALIZE, PROJ_DUCHI = 0, 1
 FLAG_BINARY_PATH = 1
 STORAGE = {"auto": 0, "f64": 1, "f64w": 2}
 MAX_K = 512
-PEER_HANDLE_BYTES = 128
+PEER_HANDLE_BYTES = 192
 
 #: every symbol include/nbmf_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -35,6 +35,7 @@ SYMBOLS = [
     "nbmf_comm_init_host", "nbmf_peer_export", "nbmf_comm_init_peer", "nbmf_comm_detach",
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
     "nbmf_set_progress", "nbmf_device_synchronize", "nbmf_small_stats", "nbmf_generate_slice", "nbmf_set_storage",
+    "nbmf_set_exchange_panels", "nbmf_set_peer_timeout_ms", "nbmf_run_batch", "nbmf_batch_stats",
 ]
 
 
@@ -93,6 +94,17 @@ def load():
             f"{path} not found: build it with `make -C nbmf_mm_amd/csrc` (needs hipcc); "
             "nbmf_mm_amd has no CPU fallback")
     lib = ctypes.CDLL(path)
+    if "NBMF_HIP_LIBRARY" in os.environ:
+        # an explicitly named build (A/B measurements against an older library): entry points it lacks raise when called
+        class _Missing:
+            def __init__(self, name):
+                self.name, self.argtypes, self.restype = name, None, None
+
+            def __call__(self, *a):
+                raise NBMFHipError(f"{path} does not export {self.name}")
+        for name in SYMBOLS:
+            if not hasattr(lib, name):
+                setattr(lib, name, _Missing(name))
     dp = POINTER(c_double)
     lib.nbmf_abi_version.restype = c_int
     lib.nbmf_last_error.restype = c_char_p
@@ -108,6 +120,9 @@ def load():
     lib.nbmf_set_factors.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.nbmf_get_factors.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.nbmf_run.argtypes = [c_void_p, c_int, c_double, c_void_p, POINTER(c_int)]
+    lib.nbmf_run_batch.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]
+    lib.nbmf_batch_stats.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.nbmf_w_only_steps.argtypes = [c_void_p, c_int]
     lib.nbmf_loss.argtypes = [c_void_p, dp]
     lib.nbmf_loglik.argtypes = [c_void_p, c_int, dp]
@@ -119,6 +134,8 @@ def load():
     lib.nbmf_peer_export.argtypes = [c_void_p, c_int, c_void_p]
     lib.nbmf_comm_init_peer.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int]
     lib.nbmf_comm_detach.argtypes = [c_void_p]
+    lib.nbmf_set_exchange_panels.argtypes = [c_void_p, c_int]
+    lib.nbmf_set_peer_timeout_ms.argtypes = [c_void_p, c_double]
     lib.nbmf_timing_enable.argtypes = [c_void_p, c_int]
     lib.nbmf_timing_get.argtypes = [c_void_p, dp, POINTER(c_int), dp, POINTER(c_int)]
     lib.nbmf_synchronize.argtypes = [c_void_p]
@@ -267,6 +284,32 @@ class Context:
         _check(self._lib.nbmf_run(self._h, int(max_iter), float(tol), losses.ctypes.data_as(c_void_p), byref(n_iter)))
         return losses[: n_iter.value].copy(), n_iter.value
 
+    def run_batch(self, alphas, betas, W0, H0, max_iter, tol):
+        """Independent fits of this context's data, one per (alpha, beta, W0, H0) -- a prior grid, restarts -- as many at
+        a time as the chip holds, in one launch per group (``nbmf_run_batch``).  ``W0`` is (P, k, m) or (k, m) (the same
+        start for every problem), ``H0`` likewise.  Returns ``(losses, n_iter, W, H)``: a list of P loss curves, an int
+        array, and the final factors (P, k, m) / (P, k, n).  Problem p's results are bitwise those of ``set_hyper`` +
+        ``set_factors`` + ``run`` + ``get_factors``."""
+        alphas = np.ascontiguousarray(np.atleast_1d(alphas), dtype=np.float64)
+        P = alphas.size
+        betas = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(np.asarray(betas, dtype=np.float64)), (P,)))
+        W0 = np.ascontiguousarray(np.broadcast_to(_f64c(W0), (P, self.k, self.m)))
+        H0 = np.ascontiguousarray(np.broadcast_to(_f64c(H0), (P, self.k, self.n)))
+        losses = np.zeros((P, int(max_iter)), dtype=np.float64)
+        n_iter = np.zeros(P, dtype=np.int32)
+        W = np.empty_like(W0)
+        H = np.empty_like(H0)
+        ptr = lambda a: a.ctypes.data_as(c_void_p)   # noqa: E731
+        _check(self._lib.nbmf_run_batch(self._h, int(P), ptr(alphas), ptr(betas), ptr(W0), ptr(H0), int(max_iter), float(tol),
+                                        ptr(losses), ptr(n_iter), ptr(W), ptr(H)))
+        return [losses[p, :n_iter[p]].copy() for p in range(P)], n_iter, W, H
+
+    def batch_stats(self):
+        """(persistent launches made by run_batch on this context, problems they served)."""
+        a, b = c_int(0), c_int(0)
+        _check(self._lib.nbmf_batch_stats(self._h, byref(a), byref(b)))
+        return a.value, b.value
+
     def w_only_steps(self, n_steps):
         _check(self._lib.nbmf_w_only_steps(self._h, int(n_steps)))
 
@@ -323,6 +366,14 @@ class Context:
             raise ValueError(f"expected {PEER_HANDLE_BYTES} handle bytes per rank")
         buf = ctypes.create_string_buffer(handles, len(handles))
         _check(self._lib.nbmf_comm_init_peer(self._h, buf, int(nranks), int(rank), int(shard_axis)))
+
+    def set_exchange_panels(self, panels=0):
+        """Row split: exchange in 1 or 2 column panels at the next attach (0 = default); same on every rank."""
+        _check(self._lib.nbmf_set_exchange_panels(self._h, int(panels)))
+
+    def set_peer_timeout_ms(self, ms=0.0):
+        """Bound on every wait of the peer transport attached next (0 = default: NBMF_PEER_TIMEOUT_MS or 30 s)."""
+        _check(self._lib.nbmf_set_peer_timeout_ms(self._h, float(ms)))
 
     def comm_detach(self):
         """Drop the attached communicator; every rank must do the same."""

@@ -476,10 +476,11 @@ _MSG_PREFIX = encode(("msg", None))[:-1]
 _ENV_SKIP = len(_MSG_PREFIX)
 
 
-def init_from_env(timeout=300.0, collective_timeout=None):
-    """The group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (see the module docstring)."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+def init_from_env(timeout=300.0, collective_timeout=None, rank=None, world=None):
+    """The group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (see the module docstring); ``rank`` /
+    ``world`` override the environment (a process that hosts several ranks, one thread each, numbers them itself)."""
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
     if world == 1:
         return SingleGroup()
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")

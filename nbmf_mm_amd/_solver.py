@@ -120,6 +120,48 @@ def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
     return W_final, H_final, losses, 0.0, n_iter
 
 
+def nbmf_mm_restarts(Y, n_components, n_init, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None, H_init=None,
+                     mask=None, random_state=None, orientation="beta-dir", eps=1e-8, projection="normalize", device=0):
+    """``n_init`` restarts of :func:`nbmf_mm_solver` (README.md:144; seeds ``random_state + r``) with ONE upload of the
+    data and ONE ``nbmf_run_batch`` call: small problems run several restarts at a time in one launch.  Every restart is
+    bit for bit the sequential call with that seed (same draws from the global generator, in the same order).  Returns
+    ``(W, H, losses, 0.0, n_iter)`` of the restart with the lowest final loss (the first one on ties) and its index."""
+    proj = _projection_code(projection)
+    if int(max_iter) < 1:
+        raise ValueError("max_iter must be >= 1")
+    if not hasattr(Y, "toarray"):
+        Y = np.asarray(Y)
+    m, n = Y.shape
+    k = int(n_components)
+    transposed = orientation == "dir-beta"
+    if transposed:
+        m, n = n, m
+        if W_init is not None and H_init is not None:
+            W_init, H_init = np.asarray(H_init).T, np.asarray(W_init).T
+    W0s, H0s = [], []
+    for r in range(int(n_init)):
+        if random_state is not None:
+            np.random.seed(random_state + r)           # restarts: consecutive seeds, each seeding the GLOBAL generator (:102-103)
+        Wi, Hi = _draw_init(m, k, n, W_init, H_init)
+        W = np.asarray(Wi, dtype=np.float64).T
+        W0s.append(W / W.sum(axis=0, keepdims=True))
+        H0s.append(np.asarray(Hi, dtype=np.float64))
+        if W0s[-1].shape != (k, m) or H0s[-1].shape != (k, n):
+            raise ValueError(f"operands could not be broadcast together: W_init/H_init give {W0s[-1].shape}, {H0s[-1].shape}; "
+                             f"expected ({k},{m}), ({k},{n})")
+    with _hip.Context(m, n, k, device=device) as ctx:
+        ctx.set_hyper(alpha, beta, eps, proj)
+        upload_any(ctx, Y, mask, transposed=transposed)
+        curves, n_iters, Ws, Hs = ctx.run_batch([alpha] * len(W0s), [beta] * len(W0s), np.stack(W0s), np.stack(H0s),
+                                                int(max_iter), float(tol))
+    best = min(range(len(curves)), key=lambda r: (curves[r][-1], r))
+    W_final, H_final = Ws[best].T, Hs[best]
+    if transposed:
+        W_final, H_final = H_final.T, W_final.T
+    W_final, H_final = _touch_up(W_final, H_final, orientation)
+    return (W_final, H_final, [float(v) for v in curves[best]], 0.0, int(n_iters[best])), best
+
+
 def _touch_up(W_final, H_final, orientation):
     """Final renormalisation only where the simplex sums drifted by more than 1e-9
     (src/nbmf_mm/_solver.py:192-213); normally a no-op."""

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -29,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -69,6 +71,15 @@
 #endif
 #ifndef NBMF_NT_CODES
 #define NBMF_NT_CODES 1   // the once-read code stream is loaded non-temporally: fewer factor-panel lines evicted from L2 (c3 HBM traffic per launch H 0.994 -> 0.971, W 0.910 -> 0.843, L 0.718 -> 0.640 GB; same speed)
+#endif
+#ifndef NBMF_ASM_NEGSEL
+#define NBMF_ASM_NEGSEL 1   // the W sweeps' (m ? a : -b) as two inline-assembly v_cndmask_b32 with the negation as a source modifier (see sel64_neg)
+#endif
+#ifndef NBMF_DMA_INTERLEAVE
+#define NBMF_DMA_INTERLEAVE 1   // the waves' LDS-DMA pieces interleaved (4 KiB of consecutive addresses per instant: c3 W-pass 2.15 -> 2.13 ms, H-pass 2.92 -> 2.91) instead of one contiguous run per wave (0)
+#endif
+#ifndef NBMF_NO_MFMA
+#define NBMF_NO_MFMA 0   // 1 = measurement build: the sweeps without their MFMAs (see NBMF_MFMA in nbmf_pass_kernel.inc)
 #endif
 #ifndef NBMF_HAZARD_SEED
 #define NBMF_HAZARD_SEED 0   // 1 = compile a kernel with a deliberate MFMA-after-inline-assembly hazard (build self-test only)
@@ -130,6 +141,7 @@ constexpr int PAD = 128;          // m and n are padded to multiples of 128 (8 r
 #define NBMF_WG_WAVES 4
 #endif
 constexpr int WG_WAVES = NBMF_WG_WAVES;   // waves (= column strips) per workgroup of the pass kernel; measured: 2-wave workgroups run 30 % slower (125 vs 179 it/s at c3)
+constexpr size_t PASS_SLACK = 65536;   // bytes allocated behind every image the sweeps stream: their prefetch runs one stage (<= 32 KiB) past the last block
 constexpr int STAGE_BYTES = 32768; // one LDS stage: NB row blocks x (T + G operand images); two stages per workgroup
 
 // ------------------------------------------------------------------------------------------
@@ -293,7 +305,25 @@ __device__ __forceinline__ double sel64_neg(lanemask_t m, double a, double b) { 
 __device__ __forceinline__ double sel64(lanemask_t m, double a, double b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : b; }
 __device__ __forceinline__ double sel64_or0(lanemask_t m, double a) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : 0.0; }
 __device__ __forceinline__ double sel64_0or(lanemask_t m, double b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? 0.0 : b; }
+// m ? a : -b is the one select that stays inline assembly (NBMF_ASM_NEGSEL): the sign flip rides on the second
+// v_cndmask_b32 as a source modifier, where hipcc spends a v_xor_b32 of its own (it splits the f64 select into 32-bit
+// halves only after the negation has become an instruction; written on the halves by hand, with a float negation for
+// the modifier to absorb, the select comes back as divergent BRANCHES) -- one vector instruction per entry of every W
+// sweep.  Its result is an MFMA operand, so the two wait states are the caller's business again: the pass kernel has
+// the product loop's LDS reads in between, the single-launch kernel an s_nop tied to the operand, and `make` checks
+// every build (tools/check_asm_mfma_hazard.py) and removes a library that gets it wrong.
+#if NBMF_ASM_NEGSEL
+__device__ __forceinline__ double sel64_neg(lanemask_t m, double a, double b) {
+  const uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+  const uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+  uint32_t lo, hi;
+  __asm__("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(blo), "v"(alo), "s"(m));
+  __asm__("v_cndmask_b32_e64 %0, -%1, %2, %3" : "=v"(hi) : "v"(bhi), "v"(ahi), "s"(m));   // the float negate modifier flips bit 31
+  return mk_double(lo, hi);
+}
+#else
 __device__ __forceinline__ double sel64_neg(lanemask_t m, double a, double b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : -b; }
+#endif
 #endif
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -358,6 +388,8 @@ struct nbmf_ctx {
   // axis 0: the K x N exchange is cut into column panels so that the second panel's all-reduce runs (on
   // stream2) while the first panel's H-update and its share of the W-pass compute
   int npanel = 1;
+  int panels_wanted = 0;            // nbmf_set_exchange_panels: 0 = default / environment
+  double peer_timeout_ms = 0;       // nbmf_set_peer_timeout_ms: 0 = default / environment
   long long pc0[3] = {0, 0, 0};     // panel column boundaries
   size_t pbase[2] = {0, 0};         // panel-major offsets into Pbuf: [P1_p (KP x wp) | P2_p (KP x wp)]
   size_t ll_index = 0;              // loglik slot, right behind panel 0 (travels with it)
@@ -396,6 +428,15 @@ struct nbmf_ctx {
     bool ready = false, disabled = false;
     int runs = 0, aborted = 0;   // statistics (nbmf_small_stats)
   } small;
+  // batched runs (nbmf_run_batch): per-problem factor images / hand-off words for as many problems as fit the chip at once
+  struct SmallBatchWs {
+    char* slab = nullptr;          // [cap] per-problem blocks, `stride` bytes apart (small_batch_layout)
+    double* table = nullptr;       // [2][cap] alpha - 1 | beta - 1 of the problems of a launch
+    double* io = nullptr;          // staging for the factors of a whole batch (up and down)
+    int cap = 0, losses_cap = 0;
+    size_t io_doubles = 0;
+    int launches = 0, problems = 0;   // statistics
+  } small_batch;
   // progress reports out of nbmf_run (nbmf_set_progress)
   nbmf_progress_fn progress = nullptr;
   void* progress_user = nullptr;
@@ -541,6 +582,21 @@ void stream_release(int device, hipStream_t st) {   // the caller has synchronis
     hipStreamDestroy(st);
 }
 
+// Wait for a stream whose work lasts milliseconds.  hipStreamSynchronize spins briefly and then sleeps on the
+// completion interrupt; about one wake-up in 70 arrives ~8.6 ms late (tools/bimodal_probe.py: the kernel's own clock
+// shows the same 35.0 ms on the device for a 3000-iteration fit whether the host saw 35.2 or 43.7 ms -- what round 2
+// took for a second, slower "speed" of the single-launch path).  For a fit that lasts 3 ms that is the run three times
+// over, so the small-problem paths poll the stream for up to `spin_ms` before they fall back to the blocking call.
+hipError_t stream_wait_spin(hipStream_t st, double spin_ms = 200.0) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > spin_ms) break;
+  }
+  return hipStreamSynchronize(st);
+}
+
 // ---- RCCL, loaded lazily so that single-GPU use has no dependency on it ---------------------
 struct Uid {
   char internal[128];
@@ -611,6 +667,10 @@ constexpr int kNcclSum = 0;       // ncclSum
 // context of a fitting size takes it over.  Freeing an exported arena and exporting a fresh allocation that
 // lands on the same address handed the peers a mapping of the OLD memory (seen as a wrong factor in the second
 // of two sharded fits in one process); a handle that stays valid for good cannot go stale.
+struct PeerOrigin {   // tail of a handle block
+  unsigned long long pid, arena, flags;
+  int device, reserved;
+};
 struct ArenaSlot {
   int device;
   size_t doubles;
@@ -647,9 +707,13 @@ int arena_acquire(int device, size_t doubles, ArenaSlot** out) {
       delete a;
       return fail(NBMF_ERR_HIP, "peer arena: %s (allocation or hipIpcGetMemHandle)", hipGetErrorString(e));
     }
-    static_assert(2 * sizeof(hipIpcMemHandle_t) <= NBMF_PEER_HANDLE_BYTES, "handle block too small");
+    // handle block: two IPC handles, then who exported them and where the memory sits in that process (a rank of
+    // the same process cannot open its own process's handles and uses the addresses instead)
+    static_assert(2 * sizeof(hipIpcMemHandle_t) + sizeof(PeerOrigin) <= NBMF_PEER_HANDLE_BYTES, "handle block too small");
     memset(a->handles, 0, sizeof a->handles);
     memcpy(a->handles, h, sizeof h);
+    const PeerOrigin origin{(unsigned long long)getpid(), (unsigned long long)a->arena, (unsigned long long)a->flags, device, 0};
+    memcpy(a->handles + sizeof h, &origin, sizeof origin);
     g_arenas.push_back(a);
     best = a;
   }
@@ -672,16 +736,22 @@ void arena_release(ArenaSlot* a) {
 }
 
 // ---- pass launch ----------------------------------------------------------------------------
-template <int KB, int DATA, int MODE, int TH = 0>
-hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
+template <int KB, int DATA, int MODE, int TH, bool TINY>
+hipError_t launch_pass_tt(const PassArgs& a, int chunks, hipStream_t st) {
   dim3 grid(a.Cb / (WG_WAVES * pass_ns(KB, DATA)), chunks);
   constexpr int lds_bytes = ((NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES) + (DATA != DATA_BIN ? LOG_TABLE_BYTES : 0);
   if (lds_bytes > 65536) {
-    hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH, TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
+  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
   return hipGetLastError();
+}
+// (eps below 1e-70 on the binary path: the variant with per-entry reciprocals and renormalisation, see pass_kernel)
+template <int KB, int DATA, int MODE, int TH = 0>
+hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
+  if (DATA == DATA_BIN && MODE != MODE_T && a.tiny_eps) return launch_pass_tt<KB, DATA, MODE, TH, DATA == DATA_BIN && MODE != MODE_T>(a, chunks, st);
+  return launch_pass_tt<KB, DATA, MODE, TH, false>(a, chunks, st);
 }
 
 // n_components > 128: the sweep of one slice with Theta read from memory (TH = 1: whole; TH = 2: the earlier
@@ -839,7 +909,11 @@ int all_reduce_inplace(nbmf_ctx* c, double* p, size_t count, hipStream_t st = nu
     const unsigned long long e = ++c->epoch;
     const long long slice = ((long long)count + c->pv.nranks - 1) / c->pv.nranks;
     const unsigned grid = (unsigned)std::min<long long>(128, std::max<long long>(1, (slice + 1023) / 1024));
-    hipLaunchKernelGGL(peer_reduce_kernel, dim3(grid), dim3(256), 0, s, c->pv, e, off, (long long)count, c->flags);
+    // (fault injection for the tests of the failure path: NBMF_PEER_FAULT=1 makes the LAST rank skip its part of
+    //  every generic exchange, as a rank whose links do not work would -- the others must time out, not hang)
+    static const bool fault = getenv("NBMF_PEER_FAULT") && atoi(getenv("NBMF_PEER_FAULT")) != 0;
+    if (!(fault && c->pv.nranks > 1 && c->pv.rank == c->pv.nranks - 1))
+      hipLaunchKernelGGL(peer_reduce_kernel, dim3(grid), dim3(256), 0, s, c->pv, e, off, (long long)count, c->flags);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, c->pv, e, c->flags);
     HIPCHK(hipGetLastError());
@@ -1442,23 +1516,25 @@ __global__ void expand_factor_kernel(const double* __restrict__ Fn, double* __re
   FG[g_index(k, x, KS, lenA)] = Fn[idx];
 }
 
-template <int KB, bool SPLIT>
+template <int KB, bool SPLIT, bool BATCH>
 const void* small_ptr(int data_kind) {
   switch (data_kind) {
-    case DATA_BIN: return (const void*)small_fit_kernel<KB, DATA_BIN, SPLIT>;
-    case DATA_F64: return (const void*)small_fit_kernel<KB, DATA_F64, SPLIT>;
-    case DATA_F64M: return (const void*)small_fit_kernel<KB, DATA_F64M, SPLIT>;
+    case DATA_BIN: return (const void*)small_fit_kernel<KB, DATA_BIN, SPLIT, BATCH>;
+    case DATA_F64: return (const void*)small_fit_kernel<KB, DATA_F64, SPLIT, BATCH>;
+    case DATA_F64M: return (const void*)small_fit_kernel<KB, DATA_F64M, SPLIT, BATCH>;
   }
   return nullptr;
 }
+const void* small_kernel_for(const nbmf_ctx* c, bool split, bool batch);
 
 // How many workgroups a strip of the H-step (sweep of Rbe blocks, Cbe strips) or of the W-step is split over: aim at
 // two tiles per wave, stay within the CUs, at most 8 parts (one partner hand-off costs ~2 us: not worth it for
 // shorter sweeps).
+constexpr int SMALL_MAX_WGS = 256;   // workgroups a persistent run may have: the hand-off words, flags and partial buffers are sized for it
 int small_parts(const nbmf_ctx* c, long long sweep_blocks, long long strips) {
   const int NW = sm_waves(c->KB);
   long long pp = (sweep_blocks + 2 * NW - 1) / (2 * NW);
-  pp = std::min<long long>(pp, std::min<long long>(8, c->cus / std::max<long long>(1, strips)));
+  pp = std::min<long long>(pp, std::min<long long>(8, std::min(c->cus, SMALL_MAX_WGS) / std::max<long long>(1, strips)));
   return (int)std::max<long long>(1, pp);
 }
 
@@ -1468,7 +1544,10 @@ int small_parts(const nbmf_ctx* c, long long sweep_blocks, long long strips) {
 // more than NBMF_SMALL_TILES tiles (default 32768, which the other bounds imply anyway: at 4080 x 2040, K = 16 the
 // single launch still runs 1.4x the five-kernel path; larger problems belong to the LDS-staged pass kernels).
 bool small_eligible(const nbmf_ctx* c, int cus) {
-  if (c->small.disabled || is_sharded(c) || c->KS != 1 || c->KB > 2 || c->timing || (c->progress && c->progress_every > 0)) return false;
+  // (a progress callback does not change the engine: the run takes milliseconds, its losses are reported right after
+  //  it, in the same batches -- so a verbose fit and a silent one give the same bits)
+  if (c->small.disabled || is_sharded(c) || c->KS != 1 || c->KB > 2 || c->timing) return false;
+  cus = std::min(cus, SMALL_MAX_WGS);   // a device reporting more CUs than the buffers were sized for uses that many of them
   if (const char* e = getenv("NBMF_PERSISTENT"))
     if (atoi(e) == 0) return false;
   const long long Rbe = (c->m + 15) / 16, Cbe = (c->n + 15) / 16;
@@ -1511,9 +1590,9 @@ int small_prepare(nbmf_ctx* c) {
   // one allocation carved up (a fit of a small problem is over in milliseconds: a dozen hipMallocs would show)
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
   const size_t g_max = 16 * SM_TPW;
-  const size_t sync_b = round_up(sizeof(unsigned long long) * (256 + 8), 256), ll_b = round_up(sizeof(double) * 2 * g_max, 256),
+  const size_t sync_b = round_up(sizeof(unsigned long long) * (SMALL_MAX_WGS + 8), 256), ll_b = round_up(sizeof(double) * 2 * g_max, 256),
                pr_b = sizeof(double) * 3 * g_max * 8 * 2, res_b = 256;
-  const size_t g_all = 256;   // most workgroups a run can have (one per CU)
+  const size_t g_all = SMALL_MAX_WGS;   // most workgroups a run can have (one per CU; small_eligible holds runs to it)
   const size_t pb_b = sizeof(double) * g_all * 2 * 16 * (size_t)c->KP, pl_b = sizeof(double) * g_all, pf_b = sizeof(unsigned long long) * g_all;
   const size_t total = 4 * fw + 4 * fh + sync_b + ll_b + pr_b + res_b + pb_b + pl_b + pf_b;
   char* base = nullptr;
@@ -1546,27 +1625,23 @@ int small_prepare(nbmf_ctx* c) {
   return NBMF_OK;
 }
 
-// Returns NBMF_OK with *handled = true when the run is complete (losses, n_iter filled, factors in the context's
-// buffers); *handled = false means "use the five-kernel path" (factors restored to their state at entry).
-int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter, bool* handled) {
-  *handled = false;
-  if (!small_eligible(c, c->cus)) return NBMF_OK;
-  if (int rc = small_prepare(c)) return rc;
-  auto& w = c->small;
-  const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
-  SmallArgs a{};
+const void* small_kernel_for(const nbmf_ctx* c, bool split, bool batch) {
+  if (c->KB == 1)
+    return batch ? (split ? small_ptr<1, true, true>(c->data_kind) : small_ptr<1, false, true>(c->data_kind))
+                 : (split ? small_ptr<1, true, false>(c->data_kind) : small_ptr<1, false, false>(c->data_kind));
+  return batch ? (split ? small_ptr<2, true, true>(c->data_kind) : small_ptr<2, false, true>(c->data_kind))
+               : (split ? small_ptr<2, true, false>(c->data_kind) : small_ptr<2, false, false>(c->data_kind));
+}
+
+// Everything in SmallArgs that a run shares with every other run on this context's data: the packed images, the
+// geometry, how strips are split over workgroups, the hyper-parameters that are not per problem.
+void small_common_args(const nbmf_ctx* c, int max_iter, double tol, SmallArgs* out) {
+  SmallArgs& a = *out;
   a.dataA = c->dataA;
   a.maskA = c->maskA;
   a.dataB = c->dataB;
   a.maskB = c->maskB;
-  a.Wn[0] = w.Wn; a.WT[0] = w.WT; a.WG[0] = w.WG; a.Hn[0] = w.Hn; a.HT[0] = w.HT; a.HG[0] = w.HG;
-  a.Wn[1] = c->Wn; a.WT[1] = c->WT; a.WG[1] = c->WG; a.Hn[1] = c->Hn; a.HT[1] = c->HT; a.HG[1] = c->HG;
   a.rowcnt = c->rowcnt;
-  a.sync = w.sync;
-  a.ll_part = w.ll_part;
-  a.prior_part = w.prior_part;
-  a.losses = c->losses_d;
-  a.result = w.result;
   a.m = c->m; a.n = c->n; a.mA = c->mA; a.nA = c->nA;
   a.K = c->k;
   a.RbA = (int)(c->mA / 16);
@@ -1578,15 +1653,13 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   a.PW = small_parts(c, a.Cbe, a.Rbe);
   if (const char* e = getenv("NBMF_SMALL_PARTS")) {   // "ph,pw" (experiments; must still satisfy small_eligible's bounds)
     int x = 0, y = 0;
-    if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= a.PH && y >= a.PW && x <= 8 && y <= 8 && a.Cbe * x <= c->cus && a.Rbe * y <= c->cus) {
+    const int cap = std::min(c->cus, SMALL_MAX_WGS);
+    if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= a.PH && y >= a.PW && x <= 8 && y <= 8 && a.Cbe * x <= cap && a.Rbe * y <= cap) {
       a.PH = x;
       a.PW = y;
     }
   }
   a.G = std::max(a.Cbe * a.PH, a.Rbe * a.PW);
-  a.part_buf = w.part_buf;
-  a.part_ll = w.part_ll;
-  a.part_flag = w.part_flag;
   a.max_iter = max_iter;
   a.projection = c->projection;
   a.tiny_eps = c->eps < 1e-70;
@@ -1600,9 +1673,30 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   double ms = 2000.0;
   if (const char* e = getenv("NBMF_SMALL_TIMEOUT_MS")) ms = std::max(1.0, atof(e));
   a.timeout = (unsigned long long)(ms * 1e5);
+}
+
+// Returns NBMF_OK with *handled = true when the run is complete (losses, n_iter filled, factors in the context's
+// buffers); *handled = false means "use the five-kernel path" (factors restored to their state at entry).
+int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter, bool* handled) {
+  *handled = false;
+  if (!small_eligible(c, c->cus)) return NBMF_OK;
+  if (int rc = small_prepare(c)) return rc;
+  auto& w = c->small;
+  const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
+  SmallArgs a{};
+  small_common_args(c, max_iter, tol, &a);
+  a.Wn[0] = w.Wn; a.WT[0] = w.WT; a.WG[0] = w.WG; a.Hn[0] = w.Hn; a.HT[0] = w.HT; a.HG[0] = w.HG;
+  a.Wn[1] = c->Wn; a.WT[1] = c->WT; a.WG[1] = c->WG; a.Hn[1] = c->Hn; a.HT[1] = c->HT; a.HG[1] = c->HG;
+  a.sync = w.sync;
+  a.ll_part = w.ll_part;
+  a.prior_part = w.prior_part;
+  a.losses = c->losses_d;
+  a.result = w.result;
+  a.part_buf = w.part_buf;
+  a.part_ll = w.part_ll;
+  a.part_flag = w.part_flag;
   const bool split = a.PH > 1 || a.PW > 1;
-  const void* f = c->KB == 1 ? (split ? small_ptr<1, true>(c->data_kind) : small_ptr<1, false>(c->data_kind))
-                             : (split ? small_ptr<2, true>(c->data_kind) : small_ptr<2, false>(c->data_kind));
+  const void* f = small_kernel_for(c, split, false);
   if (!f) return NBMF_OK;
   const int NW = sm_waves(c->KB);
   const size_t lds_bytes = sizeof(double) * ((size_t)NW * 2 * c->KB * 4 * 64 + NW * 16 + 64 + 2 * c->KP * 16) + LOG_TABLE_BYTES;
@@ -1611,31 +1705,44 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   HIPCHK(hipMemcpyAsync(w.snapW, c->Wn, fw, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(w.snapH, c->Hn, fh, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemsetAsync(w.sync, 0, sizeof(unsigned long long) * (a.G + 1), c->stream));
-  HIPCHK(hipMemsetAsync(w.part_flag, 0, sizeof(unsigned long long) * 256, c->stream));
+  HIPCHK(hipMemsetAsync(w.part_flag, 0, sizeof(unsigned long long) * SMALL_MAX_WGS, c->stream));
   HIPCHK(hipMemsetAsync(w.result, 0, sizeof(int) * 4, c->stream));
   if (getenv("NBMF_SMALL_FORCE_ABORT")) {   // tests: raise the abort word up front, so that the fall-back runs
     const unsigned long long one = 1;
     HIPCHK(hipMemcpyAsync(w.sync + a.G, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
   }
-  unsigned long long* dbg = nullptr;
+  // Whichever way this function returns from here on -- every HIPCHK below is an early return -- the stream is
+  // drained BEFORE the diagnostic buffers go back to the pool and BEFORE the CU reservation is released: a persistent
+  // kernel that is still resident must not see its buffers reused, nor another thread's kernel admitted beside it.
+  // (Declaration order: destructors run in reverse, the synchronisation first.)
+  unsigned long long *dbg = nullptr, *place = nullptr;
+  struct DiagGuard {
+    unsigned long long *&a, *&b;
+    ~DiagGuard() {
+      if (a) dfree(a);
+      if (b) dfree(b);
+    }
+  } diag_guard{dbg, place};
   if (getenv("NBMF_SMALL_DEBUG")) {
     HIPCHK(dmalloc(&dbg, sizeof(unsigned long long) * 64 * 16));
     HIPCHK(hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 64 * 16, c->stream));
     a.dbg = dbg;
   }
-  unsigned long long* place = nullptr;
   if (getenv("NBMF_SMALL_PLACEMENT")) {
     HIPCHK(dmalloc(&place, sizeof(unsigned long long) * a.G));
     a.place = place;
   }
   void* params[] = {&a};
-  SmallReservation cus_held(c->device, a.G, c->cus);   // until this function returns (it synchronises the stream first)
+  SmallReservation cus_held(c->device, a.G, std::min(c->cus, SMALL_MAX_WGS));
+  struct DrainGuard {
+    hipStream_t st;
+    ~DrainGuard() { hipStreamSynchronize(st); }
+  } drain_guard{c->stream};
   HIPCHK(hipLaunchKernel(f, dim3(a.G), dim3(64 * NW), params, lds_bytes, c->stream));
   if (place) {   // where the dispatcher put the workgroups: XCD . shader engine . CU
     std::vector<unsigned long long> h(a.G);
     HIPCHK(hipMemcpyAsync(h.data(), place, sizeof(unsigned long long) * a.G, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    dfree(place);
     fprintf(stderr, "[nbmf] placement (xcd.se.cu):");
     for (int i = 0; i < a.G; ++i)
       fprintf(stderr, " %u.%u.%u", (unsigned)(h[i] >> 32) & 15u, (unsigned)(h[i] >> 13) & 7u, (unsigned)(h[i] >> 8) & 15u);
@@ -1645,7 +1752,6 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
     unsigned long long h[64 * 16];
     HIPCHK(hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    dfree(dbg);
     double acc[8] = {0}, fine[7] = {0};
     int cnt = 0;
     for (int t = 8; t < 63 && t + 1 < max_iter; ++t) {
@@ -1665,6 +1771,12 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
       fprintf(stderr, "[nbmf]   W tiles of wave 0 in detail: issue %.2f | operands land %.2f | tile A %.2f | tile B %.2f;  H reduce+update: "
                       "wait for all waves %.2f | update %.2f | prior sums %.2f\n", fine[0] / cnt, fine[1] / cnt, fine[2] / cnt, fine[3] / cnt,
               fine[4] / cnt, fine[5] / cnt, fine[6] / cnt);
+    if (h[15] && h[63 * 16 + 15] > h[15])
+      fprintf(stderr, "[nbmf]   on the device from the first instruction to the last: %.3f ms\n", (double)(h[63 * 16 + 15] - h[15]) * 1e-5);
+    if (h[8 * 16 + 14] && h[62 * 16 + 14] && h[62 * 16] > h[8 * 16])
+      fprintf(stderr, "[nbmf]   shader clock over iterations 8..62: %.0f MHz (%llu cycles in %.2f us)\n",
+              (double)(h[62 * 16 + 14] - h[8 * 16 + 14]) / ((double)(h[62 * 16] - h[8 * 16]) * 0.01),
+              (unsigned long long)(h[62 * 16 + 14] - h[8 * 16 + 14]), (double)(h[62 * 16] - h[8 * 16]) * 0.01);
     if (cnt)
       fprintf(stderr, "[nbmf] persistent fit, workgroup 0, us per iteration part (mean of %d): H tiles %.2f | H reduce+update %.2f | barrier %.2f | "
                       "W tiles %.2f | W reduce+update %.2f | loss %.2f | barrier %.2f | loop %.2f\n", cnt, acc[0] / cnt, acc[1] / cnt,
@@ -1674,7 +1786,7 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   unsigned long long abort_word = 0;
   HIPCHK(hipMemcpyAsync(res, w.result, sizeof res, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(&abort_word, w.sync + a.G, sizeof abort_word, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(stream_wait_spin(c->stream));
   ++w.runs;
   if (res[2] != 0 || abort_word != 0 || res[0] < 1 || res[0] > max_iter) {
     // a barrier was abandoned (workgroups not co-resident for too long): back to the state at entry, and this
@@ -1703,8 +1815,184 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
     HIPCHK(hipMemcpyAsync(c->HG, w.HG, fh, hipMemcpyDeviceToDevice, c->stream));
   }
   HIPCHK(hipMemcpyAsync(losses, c->losses_d, sizeof(double) * (size_t)res[0], hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(stream_wait_spin(c->stream));
   *n_iter = res[0];
+  *handled = true;
+  if (c->progress && c->progress_every > 0)   // the reports a launch-by-launch run would have made, in the same batches
+    for (int first = 0; first < res[0]; first += c->progress_every)
+      c->progress(c->progress_user, first, std::min(c->progress_every, res[0] - first), losses + first);
+  return NBMF_OK;
+}
+
+// ---- several independent fits of the context's data in ONE persistent launch (nbmf_run_batch) -----------------------
+// Problem p gets its own two parities of factor images, hand-off words, partial buffers, loss curve and result;
+// the grid is (G workgroups) x (B problems), every workgroup on a CU of its own, and the workgroups of one problem
+// synchronise among themselves only.  B = as many problems as the chip holds at once; more run as further launches.
+// The arithmetic of a problem is exactly that of the single-problem launch (same kernel code, same G, PH, PW): a
+// batched fit is bitwise the fit nbmf_run would have produced.
+struct SmallBatchLayout {
+  size_t fw, fh, factors, ll_b, pr_b, pb_b, pl_b, sync_b, res_b, pf_b, control, off_partials, off_control, off_losses, stride;
+};
+SmallBatchLayout small_batch_layout(const nbmf_ctx* c, int losses_cap) {
+  SmallBatchLayout L{};
+  const size_t g_max = 16 * SM_TPW;
+  L.fw = (size_t)c->KP * c->mA * sizeof(double);
+  L.fh = (size_t)c->KP * c->nA * sizeof(double);
+  L.factors = 2 * (3 * L.fw + 3 * L.fh);                          // two parities of [Wn WT WG Hn HT HG]
+  L.ll_b = round_up(sizeof(double) * 2 * g_max, 256);
+  L.pr_b = sizeof(double) * 3 * g_max * 8 * 2;
+  L.pb_b = sizeof(double) * SMALL_MAX_WGS * 2 * 16 * (size_t)c->KP;
+  L.pl_b = round_up(sizeof(double) * SMALL_MAX_WGS, 256);
+  L.sync_b = round_up(sizeof(unsigned long long) * (SMALL_MAX_WGS + 8), 256);
+  L.res_b = 256;
+  L.pf_b = round_up(sizeof(unsigned long long) * SMALL_MAX_WGS, 256);
+  L.control = L.sync_b + L.res_b + L.pf_b;                        // cleared before every launch
+  L.off_partials = L.factors;
+  L.off_control = L.off_partials + L.ll_b + L.pr_b + L.pb_b + L.pl_b;
+  L.off_losses = L.off_control + L.control;
+  L.stride = round_up(L.off_losses + sizeof(double) * (size_t)losses_cap, 256);
+  return L;
+}
+
+int small_batch_prepare(nbmf_ctx* c, int cap, int max_iter) {
+  auto& b = c->small_batch;
+  if (cap > b.cap || max_iter > b.losses_cap) {
+    cap = std::max(cap, b.cap);
+    const int lcap = std::max(max_iter, b.losses_cap);
+    for (void* p : {(void*)b.slab, (void*)b.table, (void*)b.io})
+      if (p) HIPCHK(dfree(p));
+    b.slab = nullptr;
+    b.table = nullptr;
+    b.io = nullptr;
+    b.cap = b.losses_cap = 0;
+    const SmallBatchLayout L = small_batch_layout(c, lcap);
+    const size_t total = (size_t)cap * L.stride;
+    HIPCHK(dmalloc(&b.slab, total));
+    HIPCHK(hipMemsetAsync(b.slab, 0, total, c->stream));   // pad strips of the images are never written with anything but zero
+    HIPCHK(dmalloc(&b.table, sizeof(double) * 2 * (size_t)cap));   // [alpha - 1 | beta - 1] of the problems of a launch
+    b.io_doubles = (size_t)cap * ((size_t)c->k * c->m + (size_t)c->k * c->n);
+    HIPCHK(dmalloc(&b.io, sizeof(double) * b.io_doubles));
+    b.cap = cap;
+    b.losses_cap = lcap;
+  }
+  return NBMF_OK;
+}
+
+// *handled = false: the problems do not qualify for the persistent kernel (or a launch gave up): the caller runs them
+// one by one.  Nothing of the context's own factor state is touched here.
+int run_small_batch(nbmf_ctx* c, int nprob, const double* alpha, const double* beta, const double* W0, const double* H0,
+                    int max_iter, double tol, double* losses, int* n_iter, double* W_out, double* H_out, bool* handled) {
+  *handled = false;
+  if (!small_eligible(c, c->cus)) return NBMF_OK;
+  SmallArgs a{};
+  small_common_args(c, max_iter, tol, &a);
+  const int cap_cus = std::min(c->cus, SMALL_MAX_WGS);
+  int B = std::max(1, cap_cus / a.G);
+  if (const char* e = getenv("NBMF_BATCH_MAX")) B = std::max(1, std::min(B, atoi(e)));
+  B = std::min(B, nprob);
+  if (int rc = small_batch_prepare(c, B, max_iter)) return rc;
+  auto& b = c->small_batch;
+  const SmallBatchLayout L = small_batch_layout(c, b.losses_cap);
+  const bool split = a.PH > 1 || a.PW > 1;
+  const void* f = small_kernel_for(c, split, true);
+  if (!f) return NBMF_OK;
+  const int NW = sm_waves(c->KB);
+  const size_t lds_bytes = sizeof(double) * ((size_t)NW * 2 * c->KB * 4 * 64 + NW * 16 + 64 + 2 * c->KP * 16) + LOG_TABLE_BYTES;
+  HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  const size_t wsz = (size_t)c->k * c->m, hsz = (size_t)c->k * c->n;
+  // problem 0's pointers; problem p's are these plus p * stride (PP() in the kernel, prob() here)
+  {
+    char* q = b.slab;
+    for (int par = 0; par < 2; ++par) {
+      a.Wn[par] = (double*)q; q += L.fw;
+      a.WT[par] = (double*)q; q += L.fw;
+      a.WG[par] = (double*)q; q += L.fw;
+      a.Hn[par] = (double*)q; q += L.fh;
+      a.HT[par] = (double*)q; q += L.fh;
+      a.HG[par] = (double*)q; q += L.fh;
+    }
+    a.ll_part = (double*)q; q += L.ll_b;
+    a.prior_part = (double*)q; q += L.pr_b;
+    a.part_buf = (double*)q; q += L.pb_b;
+    a.part_ll = (double*)q;
+    char* ctl = b.slab + L.off_control;
+    a.sync = (unsigned long long*)ctl;
+    a.result = (int*)(ctl + L.sync_b);
+    a.part_flag = (unsigned long long*)(ctl + L.sync_b + L.res_b);
+    a.losses = (double*)(b.slab + L.off_losses);
+    a.prob_stride = L.stride;
+    a.am1s = (const double*)b.table;
+    a.bm1s = (const double*)b.table + b.cap;
+  }
+  auto prob = [&](auto* p0, int p) { return (decltype(p0))((char*)p0 + (size_t)p * L.stride); };
+  std::vector<int> res((size_t)B * 4);
+  std::vector<unsigned long long> abort_words((size_t)B);
+  std::vector<double> priors((size_t)2 * b.cap);
+  for (int p0 = 0; p0 < nprob; p0 += B) {
+    const int Bc = std::min(B, nprob - p0);
+    for (int p = 0; p < Bc; ++p) {
+      priors[(size_t)p] = alpha[p0 + p] - 1.0;
+      priors[(size_t)b.cap + p] = beta[p0 + p] - 1.0;
+    }
+    HIPCHK(hipMemcpyAsync(b.table, priors.data(), sizeof(double) * priors.size(), hipMemcpyHostToDevice, c->stream));
+    // initial factors of the whole chunk in one copy each, expanded into every problem's parity-1 images
+    HIPCHK(hipMemcpyAsync(b.io, W0 + (size_t)p0 * wsz, sizeof(double) * wsz * Bc, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(b.io + wsz * Bc, H0 + (size_t)p0 * hsz, sizeof(double) * hsz * Bc, hipMemcpyHostToDevice, c->stream));
+    for (int p = 0; p < Bc; ++p) {
+      const long long tw = (long long)c->KP * c->mA, th = (long long)c->KP * c->nA;
+      hipLaunchKernelGGL(set_factor_kernel, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, c->stream, (const double*)(b.io + wsz * p),
+                         prob(a.Wn[1], p), prob(a.WT[1], p), prob(a.WG[1], p), c->k, c->KP, c->KP, (long long)c->m, (long long)c->mA);
+      hipLaunchKernelGGL(set_factor_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, c->stream,
+                         (const double*)(b.io + wsz * Bc + hsz * p), prob(a.Hn[1], p), prob(a.HT[1], p), prob(a.HG[1], p), c->k, c->KP,
+                         c->KP, (long long)c->n, (long long)c->nA);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemset2DAsync(b.slab + L.off_control, L.stride, 0, L.control, (size_t)Bc, c->stream));   // every problem's control words
+    if (getenv("NBMF_SMALL_FORCE_ABORT")) {   // tests: the abort word of the first problem up front
+      const unsigned long long one = 1;
+      HIPCHK(hipMemcpyAsync(a.sync + a.G, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
+    }
+    void* params[] = {&a};
+    {
+      SmallReservation cus_held(c->device, a.G * Bc, cap_cus);
+      struct DrainGuard {
+        hipStream_t st;
+        ~DrainGuard() { hipStreamSynchronize(st); }
+      } drain_guard{c->stream};
+      HIPCHK(hipLaunchKernel(f, dim3(a.G, Bc), dim3(64 * NW), params, lds_bytes, c->stream));
+      // results and abort words of all problems: strided copies
+      HIPCHK(hipMemcpy2DAsync(res.data(), sizeof(int) * 4, a.result, L.stride, sizeof(int) * 4, (size_t)Bc, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpy2DAsync(abort_words.data(), sizeof(unsigned long long), a.sync + a.G, L.stride, sizeof(unsigned long long), (size_t)Bc,
+                              hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(stream_wait_spin(c->stream));
+    }
+    ++b.launches;
+    b.problems += Bc;
+    for (int p = 0; p < Bc; ++p)
+      if (res[(size_t)p * 4 + 2] != 0 || abort_words[(size_t)p] != 0 || res[(size_t)p * 4] < 1 || res[(size_t)p * 4] > max_iter) {
+        c->small.disabled = true;   // a barrier was abandoned: this context keeps to the launches from now on
+        ++c->small.aborted;
+        if (getenv("NBMF_DEBUG")) fprintf(stderr, "[nbmf] batched persistent fit abandoned (problem %d): one by one\n", p0 + p);
+        return NBMF_OK;             // *handled stays false: the caller redoes ALL problems one by one
+      }
+    // results: final factors (the parity each problem ended on) through one staging copy, the loss curves in one strided copy
+    for (int p = 0; p < Bc; ++p) {
+      const int par = res[(size_t)p * 4 + 1];
+      const long long tw = (long long)c->k * c->m, th = (long long)c->k * c->n;
+      hipLaunchKernelGGL(get_factor_kernel, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, c->stream, (const double*)prob(a.Wn[par], p),
+                         b.io + wsz * p, c->k, (long long)c->m, (long long)c->mA);
+      hipLaunchKernelGGL(get_factor_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, c->stream, (const double*)prob(a.Hn[par], p),
+                         b.io + wsz * Bc + hsz * p, c->k, (long long)c->n, (long long)c->nA);
+      n_iter[p0 + p] = res[(size_t)p * 4];
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy2DAsync(losses + (size_t)p0 * max_iter, sizeof(double) * (size_t)max_iter, a.losses, L.stride, sizeof(double) * (size_t)max_iter,
+                            (size_t)Bc, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(W_out + (size_t)p0 * wsz, b.io, sizeof(double) * wsz * Bc, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(H_out + (size_t)p0 * hsz, b.io + wsz * Bc, sizeof(double) * hsz * Bc, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(stream_wait_spin(c->stream));
+  }
+  c->small.runs += nprob;
   *handled = true;
   return NBMF_OK;
 }
@@ -1817,7 +2105,7 @@ int set_device(nbmf_ctx* c) {
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-int nbmf_abi_version(void) { return 1; }
+int nbmf_abi_version(void) { return 2; }   // 2: NBMF_PEER_HANDLE_BYTES 128 -> 192, nbmf_generate_slice, nbmf_set_storage
 
 const char* nbmf_last_error(void) { return g_err.c_str(); }
 
@@ -1871,11 +2159,11 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
 
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
   HIPCHK(dmalloc(&c->Wn, fw));
-  HIPCHK(dmalloc(&c->WT, fw));
-  HIPCHK(dmalloc(&c->WG, fw));
+  HIPCHK(dmalloc(&c->WT, fw + PASS_SLACK));   // (+ slack: the sweeps prefetch one stage past the end, see STAGE_DMA)
+  HIPCHK(dmalloc(&c->WG, fw + PASS_SLACK));
   HIPCHK(dmalloc(&c->Hn, fh));
-  HIPCHK(dmalloc(&c->HT, fh));
-  HIPCHK(dmalloc(&c->HG, fh));
+  HIPCHK(dmalloc(&c->HT, fh + PASS_SLACK));
+  HIPCHK(dmalloc(&c->HG, fh + PASS_SLACK));
   // (the pass workspaces depend on the storage path: setup_workspaces, called by nbmf_upload)
   HIPCHK(dmalloc(&c->Pbuf, 2 * fh + 64));
   c->n_prior_blocks = (int)(((size_t)c->KP * c->nA + 255) / 256);
@@ -1905,7 +2193,8 @@ int nbmf_destroy(nbmf_ctx* c) {
   arena_release((ArenaSlot*)c->arena_slot.p);   // back to the pool, never to the allocator (see ArenaSlot)
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
                   c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
-                  c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta, c->small.slab};
+                  c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta, c->small.slab, c->small_batch.slab, c->small_batch.table,
+                  c->small_batch.io};
   for (void* p : ptrs)
     if (p) dfree(p);
   for (hipEvent_t e : c->ev) hipEventDestroy(e);
@@ -1999,8 +2288,8 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
     c->data_kind = -1;
     const size_t esz = binary ? 1 : 8;
     const size_t bytes = tiles * 256 * esz;
-    HIPCHK(dmalloc(&c->dataA, bytes));
-    HIPCHK(dmalloc(&c->dataB, bytes));
+    HIPCHK(dmalloc(&c->dataA, bytes + PASS_SLACK));
+    HIPCHK(dmalloc(&c->dataB, bytes + PASS_SLACK));
     // (the pack kernel writes every tile of the padded mA x nA grid, pad entries included)
     if (kind == DATA_F64M) {
       HIPCHK(dmalloc(&c->maskA, bytes));
@@ -2085,8 +2374,8 @@ int nbmf_generate_slice(nbmf_ctx* c, uint64_t seed, double density, double obser
   }
   c->data_kind = -1;
   const size_t tiles = (size_t)(c->mA / 16) * (c->nA / 16);
-  HIPCHK(dmalloc(&c->dataA, tiles * 256));
-  HIPCHK(dmalloc(&c->dataB, tiles * 256));
+  HIPCHK(dmalloc(&c->dataA, tiles * 256 + PASS_SLACK));
+  HIPCHK(dmalloc(&c->dataB, tiles * 256 + PASS_SLACK));
   HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
   const long long RbA = c->mA / 16;
   dim3 grid((unsigned)(c->nA / 16 / 4), (unsigned)std::min<long long>(RbA, 65535), (unsigned)((RbA + 65534) / 65535));
@@ -2139,8 +2428,8 @@ int nbmf_upload_csr(nbmf_ctx* c, const int64_t* indptr, const int32_t* indices, 
   c->data_kind = -1;
   const long long RbA = c->mA / 16, RbB = c->nA / 16;
   const size_t tiles = (size_t)RbA * RbB;
-  HIPCHK(dmalloc(&c->dataA, tiles * 256));
-  HIPCHK(dmalloc(&c->dataB, tiles * 256));
+  HIPCHK(dmalloc(&c->dataA, tiles * 256 + PASS_SLACK));
+  HIPCHK(dmalloc(&c->dataB, tiles * 256 + PASS_SLACK));
   HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
   const long long dwords = (long long)tiles * 64;
   hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0, c->stream, (uint32_t*)c->dataA,
@@ -2353,6 +2642,44 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   return NBMF_OK;
 }
 
+int nbmf_run_batch(nbmf_ctx* c, int n_problems, const double* alpha, const double* beta, const double* W0, const double* H0,
+                   int max_iter, double tol, double* losses, int* n_iter, double* W_out, double* H_out) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "nbmf_upload has not been called");
+  if (n_problems < 1) return fail(NBMF_ERR_ARG, "n_problems must be >= 1");
+  if (max_iter < 1) return fail(NBMF_ERR_ARG, "max_iter must be >= 1");
+  if (!alpha || !beta || !W0 || !H0 || !losses || !n_iter || !W_out || !H_out) return fail(NBMF_ERR_ARG, "null argument");
+  if (is_sharded(c)) return fail(NBMF_ERR_STATE, "nbmf_run_batch runs on an unsharded context (nbmf_comm_detach first)");
+  if (int rc = set_device(c)) return rc;
+  {
+    bool handled = false;
+    if (int rc = run_small_batch(c, n_problems, alpha, beta, W0, H0, max_iter, tol, losses, n_iter, W_out, H_out, &handled)) return rc;
+    if (handled) return NBMF_OK;
+  }
+  // problems too large for the persistent kernel (or a run that gave up): one after the other, each exactly the
+  // nbmf_set_hyper / nbmf_set_factors / nbmf_run / nbmf_get_factors sequence
+  const double a0 = c->alpha, b0 = c->beta;
+  const size_t wsz = (size_t)c->k * c->m, hsz = (size_t)c->k * c->n;
+  int rc = NBMF_OK;
+  for (int p = 0; p < n_problems && rc == NBMF_OK; ++p) {
+    c->alpha = alpha[p];
+    c->beta = beta[p];
+    rc = nbmf_set_factors(c, W0 + (size_t)p * wsz, H0 + (size_t)p * hsz);
+    if (rc == NBMF_OK) rc = nbmf_run(c, max_iter, tol, losses + (size_t)p * max_iter, n_iter + p);
+    if (rc == NBMF_OK) rc = nbmf_get_factors(c, W_out + (size_t)p * wsz, H_out + (size_t)p * hsz);
+  }
+  c->alpha = a0;
+  c->beta = b0;
+  return rc;
+}
+
+int nbmf_batch_stats(nbmf_ctx* c, int* launches, int* problems) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (launches) *launches = c->small_batch.launches;
+  if (problems) *problems = c->small_batch.problems;
+  return NBMF_OK;
+}
+
 int nbmf_w_only_steps(nbmf_ctx* c, int n_steps) {
   if (int rc = ready(c)) return rc;
   if (n_steps < 0) return fail(NBMF_ERR_ARG, "n_steps must be >= 0");
@@ -2421,6 +2748,7 @@ int nbmf_comm_unique_id(void* id128) {
 // Shared tail of the two comm-init entry points: exchange buffers for the chosen axis and the global
 // quantities the update formulas need.
 static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));   // a stop flag left by an earlier run must not mute the exchanges below
   c->nranks = nranks;
   c->rank = rank;
   c->shard_axis = shard_axis;
@@ -2429,7 +2757,8 @@ static int comm_finish_init(nbmf_ctx* c, int nranks, int rank, int shard_axis) {
   // with one rank, where there is nothing to hide); the break-even is an all-reduce of ~70 us, which cannot
   // be timed on a one-GPU box, so the default stays one panel.
   const char* ov = getenv("NBMF_OVERLAP");
-  c->npanel = (shard_axis == 0 && c->KS == 1 && c->chunksW >= 2 && ov && atoi(ov) != 0) ? 2 : 1;
+  const bool two = c->panels_wanted ? c->panels_wanted == 2 : (ov && atoi(ov) != 0);
+  c->npanel = (shard_axis == 0 && c->KS == 1 && c->chunksW >= 2 && two) ? 2 : 1;
   c->wsplit = c->npanel == 2 ? c->chunksW / 2 : c->chunksW;
   c->pc0[0] = 0;
   c->pc0[1] = c->npanel == 2 ? (long long)c->bW_host[c->wsplit] * 16 : c->nA;
@@ -2513,6 +2842,20 @@ int nbmf_comm_init_host(nbmf_ctx* c, nbmf_host_allreduce_fn fn, void* user, int 
   return comm_finish_init(c, nranks, rank, shard_axis);
 }
 
+int nbmf_set_peer_timeout_ms(nbmf_ctx* c, double ms) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (!(ms >= 0.0)) return fail(NBMF_ERR_ARG, "timeout must be >= 0 ms");
+  c->peer_timeout_ms = ms;
+  return NBMF_OK;
+}
+
+int nbmf_set_exchange_panels(nbmf_ctx* c, int panels) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (panels < 0 || panels > 2) return fail(NBMF_ERR_ARG, "panels must be 0 (default), 1 or 2");
+  c->panels_wanted = panels;
+  return NBMF_OK;
+}
+
 int nbmf_comm_detach(nbmf_ctx* c) {
   if (!c) return fail(NBMF_ERR_ARG, "null context");
   if (int rc = set_device(c)) return rc;
@@ -2582,6 +2925,7 @@ int nbmf_comm_init_peer(nbmf_ctx* c, const void* handles, int nranks, int rank, 
   pv.rank = rank;
   double ms = 30000.0;
   if (const char* e = getenv("NBMF_PEER_TIMEOUT_MS")) ms = std::max(1.0, atof(e));
+  if (c->peer_timeout_ms > 0) ms = c->peer_timeout_ms;
   pv.timeout = (unsigned long long)(ms * 1e5);   // wall_clock64 ticks at 100 MHz
   struct Undo {   // any failure below leaves the context unattached
     nbmf_ctx* c;
@@ -2600,7 +2944,23 @@ int nbmf_comm_init_peer(nbmf_ctx* c, const void* handles, int nranks, int rank, 
       continue;
     }
     hipIpcMemHandle_t h[2];
+    PeerOrigin origin;
     memcpy(h, (const char*)handles + (size_t)j * NBMF_PEER_HANDLE_BYTES, sizeof h);
+    memcpy(&origin, (const char*)handles + (size_t)j * NBMF_PEER_HANDLE_BYTES + sizeof h, sizeof origin);
+    if (origin.pid == (unsigned long long)getpid()) {
+      // a rank of THIS process (several contexts, one host thread each): its arena is plain device memory here;
+      // if it lives on another GPU of this process, peer access makes it addressable (pooled arenas are never freed,
+      // so the address stays valid for the life of the process)
+      if (origin.device != c->device) {
+        const hipError_t e = hipDeviceEnablePeerAccess(origin.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+          return fail(NBMF_ERR_HIP, "hipDeviceEnablePeerAccess(%d) from device %d: %s", origin.device, c->device, hipGetErrorString(e));
+        (void)hipGetLastError();
+      }
+      pv.arena[j] = (double*)origin.arena;
+      pv.flag[j] = (unsigned long long*)origin.flags;
+      continue;
+    }
     void *a = nullptr, *f = nullptr;
     HIPCHK(hipIpcOpenMemHandle(&a, h[0], hipIpcMemLazyEnablePeerAccess));
     c->peer_mapped.push_back(a);
@@ -2633,6 +2993,9 @@ int nbmf_comm_init_peer(nbmf_ctx* c, const void* handles, int nranks, int rank, 
     const unsigned long long full = c->pv.timeout;
     c->pv.timeout = std::min<unsigned long long>(full, 10ull * 100000000ull);
     unsigned long long* bad = c->stats + 4;
+    // (the exchange kernels return at once while the run's stop flag is up -- and a run that ended by its stop rule
+    //  leaves it up: clear it, or the known-answer epochs of a re-attach find nothing exchanged)
+    HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
     HIPCHK(hipMemsetAsync(bad, 0, sizeof(unsigned long long), c->stream));
     for (int t = 0; t < 4; ++t) {
       hipLaunchKernelGGL(peer_selftest_fill_kernel, dim3(256), dim3(256), 0, c->stream, c->arena, cnt, rank, t);

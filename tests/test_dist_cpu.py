@@ -470,3 +470,48 @@ def test_client_refuses_a_relay_that_does_not_know_the_secret():
         rz.Group(1, 2, ("tcp", "127.0.0.1", port), timeout=10, secret=b"right")
     t.join(5)
     srv.close()
+
+
+def test_several_ranks_in_one_process_and_private_init_stream():
+    """A process may host several ranks, one thread each (bench.py --ranks-per-process; the peer transport addresses
+    same-process arenas directly): the group works between threads of one process, and the reference's init rule is
+    drawn from a PRIVATE legacy generator that yields the numbers of np.random.seed(s) + global draws, so concurrent
+    ranks do not race on the global stream (and do not disturb it)."""
+    import threading
+    from nbmf_mm_amd import _dist, _rendezvous
+    port = _free_port()
+    old = {k: os.environ.get(k) for k in ("WORLD_SIZE", "RANK", "MASTER_ADDR", "MASTER_PORT", "NBMF_RDZV_PORT", "NBMF_RDZV_SECRET")}
+    os.environ.update(WORLD_SIZE="4", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("NBMF_RDZV_PORT", None)
+    out, errors = {}, []
+
+    def body(rank):
+        try:
+            with _rendezvous.init_from_env(timeout=60, rank=rank, world=4) as g:
+                W, H = _dist.global_init(50, 30, 4, random_state=7)
+                out[rank] = (g.all_gather(rank), g.max_float(float(rank)), W, H)
+        except BaseException as e:      # noqa: BLE001
+            errors.append(repr(e))
+    try:
+        np.random.seed(123)
+        before = np.random.get_state()[1].copy()
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        assert not errors, errors
+        np.testing.assert_array_equal(np.random.get_state()[1], before)      # the global stream was not touched
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    np.random.seed(7)                                                       # the reference's rule, _solver.py:102-136
+    W0 = np.random.uniform(0.1, 0.9, (50, 4))
+    H0 = np.random.uniform(0.1, 0.9, (4, 30))
+    for r in range(4):
+        assert out[r][0] == [0, 1, 2, 3] and out[r][1] == 3.0
+        np.testing.assert_array_equal(out[r][2], W0.T / W0.T.sum(axis=0, keepdims=True))
+        np.testing.assert_array_equal(out[r][3], H0)

@@ -384,3 +384,95 @@ def test_single_launch_admission_edges(monkeypatch, m, n, k, single):
     np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=1e-12, atol=0)
     np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=0, atol=1e-12)
     np.testing.assert_allclose(out["1"][3], out["0"][3], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("shape,k,batch_max", [((300, 200), 6, None), ((300, 200), 6, "2"), ((1226, 285), 8, None), ((2600, 2300), 40, None)])
+def test_run_batch_is_bitwise_the_sequential_runs(monkeypatch, shape, k, batch_max):
+    """nbmf_run_batch: a grid of priors / several starts on one context's data.  Small problems share persistent
+    launches (as many problems at a time as the chip holds; NBMF_BATCH_MAX caps it), large ones run one after the
+    other inside the call -- either way every problem's loss curve, iteration count and factors are bit for bit
+    what set_hyper + set_factors + run + get_factors give on the same context."""
+    from nbmf_mm_amd import _hip
+    if batch_max:
+        monkeypatch.setenv("NBMF_BATCH_MAX", batch_max)
+    m, n = shape
+    g = np.random.default_rng(31)
+    Y = (g.random((m, n)) < 0.15).astype(np.float64)
+    mask = g.random((m, n)) < 0.8
+    P = 7 if m < 2000 else 3
+    alphas = np.array([0.5, 1.0, 1.2, 1.5, 2.0, 2.5, 3.0])[:P]
+    betas = np.array([3.0, 1.0, 1.2, 0.5, 2.0, 1.1, 0.7])[:P]
+    W0 = g.uniform(0.1, 0.9, (P, k, m))
+    W0 /= W0.sum(axis=1, keepdims=True)
+    H0 = g.uniform(0.1, 0.9, (P, k, n))
+    max_iter, tol = (300, 2e-3) if m < 2000 else (6, 0.0)
+    with _hip.Context(m, n, k) as ctx:
+        ctx.set_hyper(1.2, 1.2, 1e-8)
+        ctx.upload(Y, mask=mask)
+        curves, n_iters, Ws, Hs = ctx.run_batch(alphas, betas, W0, H0, max_iter, tol)
+        launches, served = ctx.batch_stats()
+        seq = []
+        for p in range(P):
+            ctx.set_hyper(alphas[p], betas[p], 1e-8)
+            ctx.set_factors(W0[p], H0[p])
+            l, ni = ctx.run(max_iter, tol)
+            seq.append((l, ni) + ctx.get_factors())
+        # the same start for every problem (one (k, m) / (k, n) pair): what the experiment driver does
+        c2, n2, W2, H2 = ctx.run_batch(alphas[:2], betas[:2], W0[0], H0[0], max_iter, tol)
+    for p in range(P):
+        l, ni, W, H = seq[p]
+        assert n_iters[p] == ni
+        np.testing.assert_array_equal(curves[p], l)
+        np.testing.assert_array_equal(Ws[p], W)
+        np.testing.assert_array_equal(Hs[p], H)
+    np.testing.assert_array_equal(c2[0], curves[0])
+    np.testing.assert_array_equal(W2[0], Ws[0])
+    if m < 2000:
+        assert len(set(int(v) for v in n_iters)) > 1          # the problems stopped at different iterations, each on its own
+        assert served >= P and launches < served                # several problems per persistent launch
+        if batch_max:
+            assert launches >= (P + 1) // 2
+    else:
+        assert (launches, served) == (0, 0)                     # too large for the persistent kernel: one after the other
+
+
+def test_run_batch_falls_back_when_a_launch_gives_up(monkeypatch):
+    from nbmf_mm_amd import _hip
+    g = np.random.default_rng(32)
+    m, n, k, P = 200, 150, 5, 4
+    Y = (g.random((m, n)) < 0.2).astype(np.float64)
+    W0 = g.uniform(0.1, 0.9, (P, k, m))
+    W0 /= W0.sum(axis=1, keepdims=True)
+    H0 = g.uniform(0.1, 0.9, (P, k, n))
+    al, be = np.linspace(1.0, 2.0, P), np.linspace(2.0, 1.0, P)
+    with _hip.Context(m, n, k) as ctx:
+        ctx.set_hyper(1.2, 1.2, 1e-8)
+        ctx.upload(Y)
+        good = ctx.run_batch(al, be, W0, H0, 25, 0.0)
+    monkeypatch.setenv("NBMF_SMALL_FORCE_ABORT", "1")
+    with _hip.Context(m, n, k) as ctx:
+        ctx.set_hyper(1.2, 1.2, 1e-8)
+        ctx.upload(Y)
+        redo = ctx.run_batch(al, be, W0, H0, 25, 0.0)           # the launch is abandoned; every problem is redone by the five kernels
+        assert ctx.small_stats()[1] >= 1
+    for p in range(P):
+        np.testing.assert_allclose(redo[0][p], good[0][p], rtol=1e-12, atol=0)   # another engine: another order of additions
+        np.testing.assert_allclose(redo[2][p], good[2][p], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(redo[3][p], good[3][p], rtol=0, atol=1e-12)
+
+
+def test_n_init_restarts_share_one_batched_call():
+    """NBMF(n_init=r): the restarts go up as one nbmf_run_batch call; the winner is bit for bit the best of the
+    sequential fits with seeds random_state, random_state + 1, ... (README.md:144)."""
+    from nbmf_mm_amd import NBMF, nbmf_mm_solver
+    g = np.random.default_rng(33)
+    X = (g.random((90, 70)) < 0.3).astype(np.float64)
+    mask = g.random(X.shape) < 0.85
+    for orient in ("beta-dir", "dir-beta"):
+        est = NBMF(n_components=5, n_init=4, random_state=9, max_iter=80, tol=1e-6, orientation=orient).fit(X, mask=mask)
+        singles = [nbmf_mm_solver(X, 5, max_iter=80, tol=1e-6, mask=mask, random_state=9 + r, orientation=orient) for r in range(4)]
+        best = min(range(4), key=lambda r: (singles[r][2][-1], r))
+        np.testing.assert_array_equal(est.W_, singles[best][0])
+        np.testing.assert_array_equal(est.components_, singles[best][1])
+        np.testing.assert_array_equal(est.loss_curve_, singles[best][2])
+        assert est.n_iter_ == singles[best][4]

@@ -245,3 +245,154 @@ def test_config5_sparse_as_dense_with_restarts():
     samp = np.sort(np.random.default_rng(10).choice(Mv, 64, replace=False))
     Ycols = np.asarray(V[samp].todense()).T                              # internal Y = V.T: columns = V's rows
     np.testing.assert_allclose(Wi[samp].T, _h_slice(Ycols, None, Wint, H_init[:, samp]), rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------
+# configs[3] WHOLE: V 262144 x 8192, K=64 -- on one context, and as 8 ranks (32768 rows each) that share the one
+# GPU of the box: 4 processes x 2 ranks (the box admits at most 6 GPU processes at once; ranks of one process are
+# host threads with a context and stream each, and the peer transport addresses their arenas directly, the other
+# processes' through HIP IPC -- both kinds of peer in every exchange).  Every rank generates ITS rows of the same
+# global matrix on the device (nbmf_generate_slice), so the sharded runs can be held against the one-context run.
+# ------------------------------------------------------------------------------------------------------
+C4 = dict(M=262144, N=8192, K=64, seed=3, dens=0.25, obs=0.9, tol_stop=2e-3, it_stop=12)
+
+
+def _c4_init():
+    from bench import init_factors
+    return init_factors(C4["M"], C4["N"], C4["K"], seed=0)
+
+
+def _c4_rank(rank, world, port, transports, W0, H0, out):
+    """One rank of the 8: returns per transport the tol=0 losses, the stop-rule run's (n_iter, losses), the
+    replicated H of both and a row sample of its W."""
+    from nbmf_mm_amd import _dist, _hip, _rendezvous
+    M, N, K = C4["M"], C4["N"], C4["K"]
+    group = _rendezvous.Group(rank, world, ("tcp", "127.0.0.1", port), timeout=120, secret=b"tests-%d" % port)
+    try:
+        r0, r1 = _dist.shard_bounds(M, world, rank)
+        with _hip.Context(r1 - r0, N, K) as ctx:
+            ctx.set_hyper(ALPHA, BETA, EPS)
+            ctx.generate(C4["seed"], density=C4["dens"], observed=C4["obs"], row0=r0, col0=0, n_global=N)
+            res = {"n_obs": ctx.n_obs(), "rows": (r0, r1)}
+            for tr in transports:
+                used = _dist.attach_comm(ctx, group, tr)
+                assert used == tr
+                ctx.set_factors(np.ascontiguousarray(W0[:, r0:r1]), H0)
+                l0, n0 = ctx.run(3, 0.0)
+                Wa, Ha = ctx.get_factors()
+                entry = {"tol0": (l0, Ha, Wa[:, ::61].copy())}
+                if tr != "host":
+                    ctx.set_factors(np.ascontiguousarray(W0[:, r0:r1]), H0)
+                    ls, ns = ctx.run(C4["it_stop"], C4["tol_stop"])
+                    Ws, Hs = ctx.get_factors()
+                    entry["stop"] = (ns, ls, Hs, Ws[:, ::61].copy())
+                res[tr] = entry
+                ctx.comm_detach()
+        out[rank] = res
+    finally:
+        group.close()
+
+
+def _c4_process(first_rank, ranks_here, world, port, transports, q):
+    import threading
+    import traceback
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # in-kernel waits between ranks of this process: no shared hardware queue
+    os.environ.setdefault("NBMF_PEER_TIMEOUT_MS", "60000")
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    W0, H0 = _c4_init()
+    out, errors = {}, []
+
+    def body(rank):
+        try:
+            _c4_rank(rank, world, port, transports, W0, H0, out)
+        except BaseException:
+            errors.append(traceback.format_exc())
+    threads = [threading.Thread(target=body, args=(first_rank + t,)) for t in range(ranks_here)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    q.put((first_rank, out, errors))
+
+
+def test_config4_whole_on_one_gpu_and_as_eight_ranks_sharing_it():
+    import multiprocessing as mp
+    import socket
+    from nbmf_mm_amd import _hip
+    M, N, K = C4["M"], C4["N"], C4["K"]
+    W0, H0 = _c4_init()
+    # ---- one context holds the whole matrix
+    with _hip.Context(M, N, K) as ctx:
+        ctx.set_hyper(ALPHA, BETA, EPS)
+        ctx.generate(C4["seed"], density=C4["dens"], observed=C4["obs"])
+        n_obs = ctx.n_obs()
+        assert abs(n_obs / (M * N) - C4["obs"]) < 1e-3
+        ctx.set_factors(W0, H0)
+        loss0 = ctx.loss()
+        l1, _ = ctx.run(1, 0.0)
+        W1, H1 = ctx.get_factors()
+        ctx.set_factors(W0, H0)
+        l3, _ = ctx.run(3, 0.0)
+        W3, H3 = ctx.get_factors()
+        ctx.set_factors(W0, H0)
+        l3b, _ = ctx.run(3, 0.0)
+        W3b, H3b = ctx.get_factors()
+        ctx.set_factors(W0, H0)
+        ls, ns = ctx.run(C4["it_stop"], C4["tol_stop"])
+        Ws, Hs = ctx.get_factors()
+    # slice-exact first iteration against the NumPy twin of the generator + the oracle's arithmetic
+    r = np.random.default_rng(12)
+    cols = np.sort(r.choice(N, 64, replace=False))
+    rows = np.sort(r.choice(M, 96, replace=False))
+    Yc, Mc = _hip.synthetic_reference(M, N, C4["seed"], C4["dens"], C4["obs"], cols=cols)
+    np.testing.assert_allclose(H1[:, cols], _h_slice(Yc, Mc.astype(np.float64), W0, H0[:, cols]), rtol=0, atol=1e-12)
+    Yr, Mr = _hip.synthetic_reference(M, N, C4["seed"], C4["dens"], C4["obs"], rows=rows)
+    Wn = _w_bracket(Yr, Mr.astype(np.float64), W0[:, rows], H1) / N
+    np.testing.assert_allclose(W1[:, rows], Wn / Wn.sum(axis=0, keepdims=True), rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(l1, l3[:1])
+    assert _monotone(np.concatenate([[loss0], l3])) and _monotone(ls)
+    np.testing.assert_array_equal(l3, l3b)
+    np.testing.assert_array_equal(W3, W3b)
+    np.testing.assert_array_equal(H3, H3b)
+    assert 2 <= ns <= C4["it_stop"]
+    # ---- the same matrix as 8 ranks on this GPU: 4 processes x 2 ranks, three transports
+    world, per = 8, 2
+    transports = ("peer", "peer2", "host")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_c4_process, args=(p0, per, world, port, transports, q)) for p0 in range(0, world, per)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    ranks = {}
+    for _, out, errors in got:
+        assert not errors, "\n".join(errors)
+        ranks.update(out)
+    assert sorted(ranks) == list(range(world))
+    assert sum(ranks[k]["n_obs"] for k in ranks) == n_obs                     # the shards tile the same matrix
+    for tr in transports:
+        for k in range(world):
+            l0, Ha, Wsamp = ranks[k][tr]["tol0"]
+            r0, r1 = ranks[k]["rows"]
+            np.testing.assert_allclose(l0, l3, rtol=1e-12, atol=0)               # the one-context curve
+            np.testing.assert_allclose(Ha, H3, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(Wsamp, W3[:, r0:r1][:, ::61], rtol=0, atol=1e-12)
+            np.testing.assert_array_equal(l0, ranks[0][tr]["tol0"][0])           # identical on every rank, bit for bit
+            np.testing.assert_array_equal(Ha, ranks[0][tr]["tol0"][1])
+            if tr != "host":
+                n_k, l_k, H_k, W_k = ranks[k][tr]["stop"]
+                assert n_k == ns                                                  # the stop rule fires at the same iteration
+                np.testing.assert_allclose(l_k, ls, rtol=1e-12, atol=0)
+                np.testing.assert_allclose(H_k, Hs, rtol=0, atol=1e-12)          # factors of iteration ns, not ns + 1
+                np.testing.assert_allclose(W_k, Ws[:, r0:r1][:, ::61], rtol=0, atol=1e-12)
+                np.testing.assert_array_equal(H_k, ranks[0][tr]["stop"][2])
+    # peer and peer2 move the same sums in the same (rank) order: the same bits
+    np.testing.assert_array_equal(ranks[0]["peer"]["tol0"][1], ranks[0]["peer2"]["tol0"][1])

@@ -283,3 +283,28 @@ def test_many_sharded_fits_in_one_process():
         np.testing.assert_allclose(W, W1, rtol=0, atol=1e-12, err_msg=f"fit {i}: {shard} k={k}")
         np.testing.assert_allclose(H, H1, rtol=0, atol=1e-12, err_msg=f"fit {i}: {shard} k={k}")
         np.testing.assert_allclose(res[1][i][2], l1, rtol=1e-10, atol=0)
+
+
+def test_bench_is_bounded_when_the_peer_transport_attaches_nowhere():
+    """bench.py's transport selection with a peer transport that cannot exchange (fault injection: the last rank skips
+    its part of every generic exchange, so the known-answer epochs at attach time starve): every rank must get the same
+    answer within the short probe deadline -- not 30 s per attempt -- and the run goes on over the next transport.  RCCL
+    refuses two ranks on one device, so on this box that is the host transport; the line says which."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NBMF_PEER_FAULT="1")
+    env.pop("NBMF_PEER_TIMEOUT_MS", None)                 # the default (30 s) for the run itself, the probe deadline for the probes
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--M", "4096", "--N", "2048",
+                        "--K", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["replicas_identical"] is True and line["loss_monotone"] is True
+    assert not line["config"]["transport"].startswith("peer")          # the faulty transport was not chosen
+    assert "peer" not in (line["config"]["transport_trials_s_per_5_iterations"] or {})
+    assert wall < 90.0, f"transport selection with a dead peer transport took {wall:.0f} s"

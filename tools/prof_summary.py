@@ -43,8 +43,10 @@ def main(root):
 
 
 def derived(root):
-    """MFMA utilisation, clock and HBM rate of the pass kernels from the PMC passes (each pass is its own
-    run, so each quantity uses the duration of the run it was collected in)."""
+    """Per launch of every pass kernel, from the PMC passes (each pass is its own run, so each quantity uses the
+    duration of the run it was collected in): clock, MFMA-busy share of all SIMD cycles, what a 16x16 tile costs
+    (SIMD cycles, of which MFMA; vector instructions besides the MFMAs; scalar / LDS / branch instructions), where the
+    waves' time goes (parked at a wait or barrier / waiting to issue / issuing) and the HBM traffic."""
     vals = collections.defaultdict(dict)
     for d in sorted(glob.glob(f"{root}/pmc_*")):
         for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
@@ -62,18 +64,45 @@ def derived(root):
     print("\n## derived (per launch)\n")
     for k in sorted(vals):
         v = vals[k]
+        get = lambda c: v[c][0] if c in v else None   # noqa: E731
         out = [k]
+        m = re.search(r"K=(\d+),\w+,([HWLT])", k)
+        per_tile = None
+        if m:
+            K, mode = int(m.group(1)), m.group(2)
+            per_tile = {"H": 3 * K // 4, "W": K // 2, "L": K // 4, "T": K // 4}[mode]
         if "GRBM_GUI_ACTIVE" in v:
             cyc, t = v["GRBM_GUI_ACTIVE"][0] / 8.0, v["GRBM_GUI_ACTIVE"][1]
             out.append("clock %.2f GHz" % (cyc / t / 1e9))
             if "SQ_VALU_MFMA_BUSY_CYCLES" in v:
                 out.append("MFMA busy %.1f %% of SIMD cycles (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"
                            % (100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (cyc * 1024)))
+            if per_tile and get("SQ_INSTS_MFMA"):
+                tiles = get("SQ_INSTS_MFMA") / per_tile
+                line = "per 16x16 tile: %.0f SIMD cycles, %d of them MFMA (%d x 64)" % (cyc * 1024 / tiles, 64 * per_tile, per_tile)
+                if get("SQ_INSTS_VALU"):
+                    line += ", %.1f vector instructions besides the MFMAs" % ((get("SQ_INSTS_VALU") - get("SQ_INSTS_MFMA")) / tiles)
+                for cname, label in (("SQ_INSTS_SALU", "scalar"), ("SQ_INSTS_LDS", "LDS"), ("SQ_INSTS_VMEM", "VMEM"), ("SQ_INSTS_BRANCH", "branch")):
+                    if get(cname):
+                        line += ", %.1f %s" % (get(cname) / tiles, label)
+                out.append(line)
+        if get("SQ_WAVE_CYCLES"):
+            wc = get("SQ_WAVE_CYCLES")
+            parts = []
+            for cname, label in (("SQ_WAIT_ANY", "parked at a wait / barrier"), ("SQ_WAIT_INST_ANY", "waiting to issue")):
+                if get(cname):
+                    parts.append("%.1f %% %s" % (100.0 * get(cname) / wc, label))
+            if get("SQ_ACTIVE_INST_ANY"):
+                parts.append("%.1f %% issuing" % (100.0 * get("SQ_ACTIVE_INST_ANY") / wc))
+            if parts:
+                out.append("wave time: " + ", ".join(parts) + " (of SQ_WAVE_CYCLES)")
+        if get("SQ_LDS_BANK_CONFLICT") is not None and get("SQ_LDS_IDX_ACTIVE"):
+            out.append("LDS bank conflicts %.2f %% of LDS cycles" % (100.0 * get("SQ_LDS_BANK_CONFLICT") / get("SQ_LDS_IDX_ACTIVE")))
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             b = (2.0 * v["FETCH_SIZE"][0] + v["WRITE_SIZE"][0]) * 1024.0
             out.append("HBM traffic %.3f GB = %.2f TB/s ((2 x FETCH_SIZE + WRITE_SIZE) KiB over the fetch run's duration)"
                        % (b / 1e9, b / v["FETCH_SIZE"][1] / 1e12))
-        print("  " + "; ".join(out))
+        print("  " + ";\n      ".join(out))
 
 
 def sidecar(root, out_json):
