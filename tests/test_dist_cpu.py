@@ -154,6 +154,12 @@ class _StubCtx:
     def comm_detach(self):
         self.calls.append("detach")
 
+    def set_exchange_panels(self, panels=0):     # per-context settings of the real Context: recorded apart from the calls
+        self.panels = panels
+
+    def set_peer_timeout_ms(self, ms=0.0):
+        self.peer_timeout_ms = ms
+
 
 def _worker_negotiate(rank, world, port, q, kind):
     import sys
