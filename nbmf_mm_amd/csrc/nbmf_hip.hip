@@ -78,6 +78,9 @@
 #ifndef NBMF_DMA_INTERLEAVE
 #define NBMF_DMA_INTERLEAVE 1   // the waves' LDS-DMA pieces interleaved (4 KiB of consecutive addresses per instant: c3 W-pass 2.15 -> 2.13 ms, H-pass 2.92 -> 2.91) instead of one contiguous run per wave (0)
 #endif
+#ifndef NBMF_MASK_PREFETCH
+#define NBMF_MASK_PREFETCH 8   // binary sweeps: row blocks ahead of the tile in hand at which the lane-mask records are pulled into the L2 (0 = off)
+#endif
 #ifndef NBMF_NO_MFMA
 #define NBMF_NO_MFMA 0   // 1 = measurement build: the sweeps without their MFMAs (see NBMF_MFMA in nbmf_pass_kernel.inc)
 #endif
@@ -355,6 +358,7 @@ struct nbmf_ctx {
   int data_kind = -1;   // -1 = nothing uploaded
   int storage = NBMF_STORAGE_AUTO;   // storage path the next nbmf_upload is held to (nbmf_set_storage)
   void *dataA = nullptr, *dataB = nullptr, *maskA = nullptr, *maskB = nullptr;
+  unsigned long long *bitsA = nullptr, *bitsB = nullptr;   // binary path: the lane-mask images the sweeps read (built from the codes)
   double n_obs = 0, n_obs_global = 0;
   double* rowcnt = nullptr;
   double *Wn = nullptr, *WT = nullptr, *WG = nullptr, *Hn = nullptr, *HT = nullptr, *HG = nullptr;
@@ -840,7 +844,8 @@ void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int* chun
   //  100 x 500 with K = 6: 37.4 -> 26.2 us per iteration (26 700 -> 38 100 iterations/s); the 36-fit
   //  perplexity grid on the lastfm-sized matrix 0.63 -> 0.33 s.)
   // (ns = strips per wave: a workgroup of the two-strip kernels does a 64-block sweep's work in 32 blocks)
-  const int min_blocks = (long long)strips_groups * ns * ((Rb + 63) / 64) >= 512 ? 64 / ns : 8;
+  int min_blocks = (long long)strips_groups * ns * ((Rb + 63) / 64) >= 512 ? 64 / ns : 8;
+  if (const char* e = getenv("NBMF_MIN_BLOCKS")) min_blocks = std::max(NB, atoi(e));   // (tuning experiments only)
   ch = std::max(ch, std::min(Rb, min_blocks));
   ch = (int)round_up(ch, NB);
   *CH = ch;
@@ -930,6 +935,12 @@ int all_reduce_inplace(nbmf_ctx* c, double* p, size_t count, hipStream_t st = nu
 
 inline bool is_sharded(const nbmf_ctx* c) { return c->comm || c->host_reduce || c->peer; }
 
+// what a sweep reads of the data: the lane-mask image on the binary path, the double tiles otherwise
+inline const void* sweep_image(const nbmf_ctx* c, int image) {
+  if (c->data_kind == DATA_BIN) return image == 0 ? (const void*)c->bitsA : (const void*)c->bitsB;
+  return image == 0 ? c->dataA : c->dataB;
+}
+
 // column strips one workgroup of the pass kernels covers (4 waves x 1 or 2 strips per wave, see pass_ns)
 inline int wg_strips(const nbmf_ctx* c) { return WG_WAVES * pass_ns(c->KS > 1 ? 8 : c->KB, c->data_kind); }
 
@@ -1009,7 +1020,7 @@ int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int cli
   for (int step = 0; step < (with_products ? c->KS : 1); ++step) {
     const int sl = step == 0 ? last : step - 1;
     PassArgs a{};
-    a.data = c->dataA;
+    a.data = sweep_image(c, 0);
     a.mask = c->maskA;
     a.LT = c->WT + (size_t)sl * SLICE_K * c->mA;
     a.LG = c->WG + (size_t)sl * SLICE_K * c->mA;
@@ -1049,7 +1060,7 @@ int enqueue_h_pass(nbmf_ctx* c) {
     return enqueue_exchange_after_sweep(c, a, /*with_products=*/true, /*strict=*/0);
   }
   PassArgs a{};
-  a.data = c->dataA;
+  a.data = sweep_image(c, 0);
   a.mask = c->maskA;
   a.LT = c->WT;
   a.LG = c->WG;
@@ -1082,7 +1093,7 @@ int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0) {
     return enqueue_exchange_after_sweep(c, a, /*with_products=*/false, strict);
   }
   PassArgs a{};
-  a.data = c->dataA;
+  a.data = sweep_image(c, 0);
   a.mask = c->maskA;
   a.LT = c->WT;
   a.LG = c->WG;
@@ -1154,7 +1165,7 @@ int enqueue_h_update(nbmf_ctx* c) {
 
 PassArgs w_pass_args(nbmf_ctx* c) {
   PassArgs a{};
-  a.data = c->dataB;
+  a.data = sweep_image(c, 1);
   a.mask = c->maskB;
   a.LT = c->HT;
   a.LG = c->HG;
@@ -1236,7 +1247,7 @@ int enqueue_w_step(nbmf_ctx* c, int projection);
 int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   const size_t per = (size_t)c->KP * c->nA;
   PassArgs a{};
-  a.data = c->dataA;
+  a.data = sweep_image(c, 0);
   a.mask = c->maskA;
   a.LT = c->WT;
   a.LG = c->WG;
@@ -1368,7 +1379,7 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
   const size_t per = (size_t)c->KP * c->nA;
   // ---- H-pass (all columns)
   PassArgs a{};
-  a.data = c->dataA;
+  a.data = sweep_image(c, 0);
   a.mask = c->maskA;
   a.LT = c->WT;
   a.LG = c->WG;
@@ -2036,6 +2047,21 @@ int setup_workspaces(nbmf_ctx* c) {
     if (*p) HIPCHK(dfree(*p));
     *p = nullptr;
   }
+  // binary path: the lane-mask images of the two code images (what the sweeps read)
+  for (unsigned long long** p : {&c->bitsA, &c->bitsB}) {
+    if (*p) HIPCHK(dfree(*p));
+    *p = nullptr;
+  }
+  if (c->data_kind == DATA_BIN) {
+    const long long n_tiles = (long long)(c->mA / 16) * (c->nA / 16);
+    HIPCHK(dmalloc(&c->bitsA, sizeof(unsigned long long) * 8 * (size_t)n_tiles));
+    HIPCHK(dmalloc(&c->bitsB, sizeof(unsigned long long) * 8 * (size_t)n_tiles));
+    for (int image = 0; image < 2; ++image) {
+      hipLaunchKernelGGL(mask_build_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, c->stream,
+                         (const uint32_t*)(image == 0 ? c->dataA : c->dataB), image == 0 ? c->bitsA : c->bitsB, n_tiles);
+      HIPCHK(hipGetLastError());
+    }
+  }
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
   HIPCHK(dmalloc(&c->slabH, 2 * (size_t)c->chunksH * fh));
   HIPCHK(dmalloc(&c->slabW, (size_t)c->chunksW * fw));
@@ -2194,7 +2220,7 @@ int nbmf_destroy(nbmf_ctx* c) {
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
                   c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
                   c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta, c->small.slab, c->small_batch.slab, c->small_batch.table,
-                  c->small_batch.io};
+                  c->small_batch.io, c->bitsA, c->bitsB};
   for (void* p : ptrs)
     if (p) dfree(p);
   for (hipEvent_t e : c->ev) hipEventDestroy(e);

@@ -476,3 +476,70 @@ def test_n_init_restarts_share_one_batched_call():
         np.testing.assert_array_equal(est.components_, singles[best][1])
         np.testing.assert_array_equal(est.loss_curve_, singles[best][2])
         assert est.n_iter_ == singles[best][4]
+
+
+def test_storage_paths_agree_and_can_be_chosen_through_the_api():
+    """nbmf_set_storage: the same binary data and bool mask on the byte-code path (automatic), forced onto the 8-byte
+    path (the reference's arithmetic for real-valued V: two quotients and two logarithms per entry) and onto the 16-byte
+    path (float64 weight tiles) -- three kernels families, one fit.  Also without a mask (all-ones weights)."""
+    from nbmf_mm_amd import _hip
+    from oracle import nbmf_oracle as orc
+    g = np.random.default_rng(41)
+    m, n, k = 333, 270, 20
+    Y = (g.random((m, n)) < 0.3).astype(np.float64)
+    mask = g.random((m, n)) < 0.85
+    W0 = g.uniform(0.1, 0.9, (k, m))
+    W0 /= W0.sum(axis=0, keepdims=True)
+    H0 = g.uniform(0.1, 0.9, (k, n))
+    for mk in (mask, None):
+        got = {}
+        for storage in ("auto", "f64", "f64w"):
+            with _hip.Context(m, n, k) as ctx:
+                ctx.set_hyper(1.3, 1.1, 1e-8)
+                ctx.set_storage(storage)
+                binary = ctx.upload(Y, mask=mk)
+                assert binary == (storage == "auto")
+                ctx.set_factors(W0, H0)
+                losses, _ = ctx.run(12, 0.0)
+                got[storage] = (losses,) + ctx.get_factors()
+        Wr, Hr, lr = W0, H0, []
+        mf = None if mk is None else mk.astype(np.float64)
+        for _ in range(12):
+            Wr, Hr = orc.mm_step(Y, Wr, Hr, mf, 1.3, 1.1, 1e-8)
+            lr.append(orc.mm_loss(Y, Wr, Hr, mf, 1.3, 1.1, 1e-8))
+        for storage, (l, W, H) in got.items():
+            np.testing.assert_allclose(l, lr, rtol=1e-10, atol=0, err_msg=storage)
+            np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-9, err_msg=storage)
+            np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-9, err_msg=storage)
+    with pytest.raises(ValueError):
+        _hip.Context(8, 8, 2).set_storage("f32")
+
+
+def test_generate_slice_is_the_slice_of_the_global_matrix():
+    """nbmf_generate_slice: a context holding rows [row0, row0+m) x columns [col0, col0+n) of a matrix n_global wide
+    generates exactly those entries of what nbmf_generate gives a context holding the whole matrix (checked through
+    the NumPy twin of the generator and one MM iteration against the oracle) -- the basis of the sharded runs at sizes
+    no host array can hold."""
+    from nbmf_mm_amd import _hip
+    from oracle import nbmf_oracle as orc
+    M, N, k, seed = 1500, 900, 12, 77
+    g = np.random.default_rng(42)
+    for (r0, m, c0, n) in [(0, 1500, 0, 900), (640, 500, 0, 900), (1000, 500, 37, 300), (1499, 1, 899, 1)]:
+        Yg, Mg = _hip.synthetic_reference(M, N, seed, 0.2, 0.8, rows=np.arange(r0, r0 + m), cols=np.arange(c0, c0 + n))
+        W0 = g.uniform(0.1, 0.9, (k, m))
+        W0 /= W0.sum(axis=0, keepdims=True)
+        H0 = g.uniform(0.1, 0.9, (k, n))
+        with _hip.Context(m, n, k) as ctx:
+            ctx.set_hyper(1.2, 1.2, 1e-8)
+            ctx.generate(seed, density=0.2, observed=0.8, row0=r0, col0=c0, n_global=N)
+            assert ctx.n_obs() == float(Mg.sum())
+            ctx.set_factors(W0, H0)
+            l, _ = ctx.run(1, 0.0)
+            W1, H1 = ctx.get_factors()
+        Wr, Hr = orc.mm_step(Yg, W0, H0, Mg.astype(np.float64), 1.2, 1.2, 1e-8)
+        np.testing.assert_allclose(W1, Wr, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(H1, Hr, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(l[0], orc.mm_loss(Yg, Wr, Hr, Mg.astype(np.float64), 1.2, 1.2, 1e-8), rtol=1e-12)
+    with pytest.raises(ValueError):
+        with _hip.Context(10, 10, 2) as ctx:
+            ctx.generate(1, row0=0, col0=5, n_global=12)          # the slice does not fit the global width
