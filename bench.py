@@ -422,7 +422,7 @@ def run_rank(args, rank, local_rank, world):
                        "note": "projection=duchi is the README-only extension BASELINE configs[2] names (no reference code: "
                                "property-tested, parity unpinned); normalize_value is the reference's own path "
                                "(_solver.py:54,57) timed in the same run on the same data",
-                       "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "u8 tile codes" if binary_path else ("f64 tiles + f64 weight tiles" if args.storage == "f64w" else "f64 tiles"),
+                       "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "lane-mask records for the sweeps (2 bits per entry) + u8 tile codes for the per-lane kernels" if binary_path else ("f64 tiles + f64 weight tiles" if args.storage == "f64w" else "f64 tiles"),
                        "devices": devices,
                        "transport": transport, "transport_trials_s_per_5_iterations": trials, "transport_check": transport_check,
                        "sharding": (f"rows/{world} ({transport}: " + ("reduce-scatter of 2*K*N+1 doubles fused with the H-update, K*N back"
@@ -434,11 +434,11 @@ def run_rank(args, rank, local_rank, world):
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                          "peak_measured": PEAK_MEASURED_TFLOPS, "frac_of_measured": achieved / PEAK_MEASURED_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_unit": "bytes per launch (PMC: (2*FETCH_SIZE + WRITE_SIZE) KiB; algorithmic: "
-                                         "m*N code bytes + 2*chunks*K*N*8 slab bytes = %.3g; with the factor reads every launch "
-                                         "also makes -- the stationary factor once per XCD and chunk pair, each chunk's two operand "
-                                         "images once: >= %.3g, DESIGN.md 4.1)"
-                                         % (m_loc * N + 2.0 * 16 * K * N * 8, m_loc * N + 2.0 * 16 * K * N * 8 + 8.0 * K * N * 8 + 2.0 * m_loc * K * 8),
+                         "traffic_unit": "bytes per launch (PMC: (2*FETCH_SIZE + WRITE_SIZE) KiB; algorithmic: the data image the "
+                                         "sweep reads -- lane-mask records, m*N/4 bytes, on the binary path -- + 2*chunks*K*N*8 slab bytes = "
+                                         "%.3g; beyond that every launch reads the factor panels, once per XCD and chunk pair while they fit "
+                                         "the L2s: DESIGN.md 4.1, 5)" % (m_loc * N * (0.25 if binary_path else (16 if args.storage == "f64w" else 8))
+                                                                        + 2.0 * 16 * K * N * 8),
                          "hpass_ms": h_ms, "wpass_ms": w_ms,
                          # the whole iteration against the same peak, two ways: EXECUTED MFMA flop (the W-pass runs one
                          # back-product instead of two, SURVEY N4: 6 + 4 = 10*m*N*K) -- the utilisation figure -- and the
