@@ -20,6 +20,7 @@
 // No BLAS, no PyTorch: plain HIP + (optionally, loaded at run time) RCCL.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <dlfcn.h>
 #include <unistd.h>
@@ -77,6 +78,9 @@
 #endif
 #ifndef NBMF_DMA_INTERLEAVE
 #define NBMF_DMA_INTERLEAVE 1   // the waves' LDS-DMA pieces interleaved (4 KiB of consecutive addresses per instant: c3 W-pass 2.15 -> 2.13 ms, H-pass 2.92 -> 2.91) instead of one contiguous run per wave (0)
+#endif
+#ifndef NBMF_STAGE_UNROLL
+#define NBMF_STAGE_UNROLL 2   // stages per trip of the sweep loop: with two, the LDS buffer index and the hand-over of the lane-mask registers are static
 #endif
 #ifndef NBMF_MASK_PREFETCH
 #define NBMF_MASK_PREFETCH 8   // binary sweeps: row blocks ahead of the tile in hand at which the lane-mask records are pulled into the L2 (0 = off)
@@ -740,6 +744,11 @@ void arena_release(ArenaSlot* a) {
 }
 
 // ---- pass launch ----------------------------------------------------------------------------
+// Timing (nbmf_timing_enable): a sweep that is ONE launch carries its two events in its own dispatch packet
+// (hipExtLaunchKernelGGL: start and end of that kernel, no barrier packets in front of and behind it, which at
+// configs[1] cost ~4.5 us each, 5 % of the iteration); EvScope puts them here, the next pass launch of this thread
+// takes them.  Sweeps of several launches are bracketed by recorded events as before.
+thread_local hipEvent_t tl_attach_start = nullptr, tl_attach_stop = nullptr;
 template <int KB, int DATA, int MODE, int TH, bool TINY>
 hipError_t launch_pass_tt(const PassArgs& a, int chunks, hipStream_t st) {
   dim3 grid(a.Cb / (WG_WAVES * pass_ns(KB, DATA)), chunks);
@@ -747,6 +756,12 @@ hipError_t launch_pass_tt(const PassArgs& a, int chunks, hipStream_t st) {
   if (lds_bytes > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH, TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
+  }
+  if (tl_attach_start) {
+    hipEvent_t e0 = tl_attach_start, e1 = tl_attach_stop;
+    tl_attach_start = tl_attach_stop = nullptr;
+    hipExtLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, e0, e1, 0, a);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
   return hipGetLastError();
@@ -869,8 +884,11 @@ struct EvScope {
   nbmf_ctx* c;
   int kind;
   size_t slot = (size_t)-1;
+  bool attach;
   // count = false: add the time to `kind` but do not count a launch (second part of a split sweep)
-  EvScope(nbmf_ctx* c_, int kind_, bool count = true) : c(c_), kind(kind_ | (count ? 0 : 0x100)) {
+  // attach = true: the scope holds exactly one pass launch, on c->stream, which carries the events itself (launch_pass_tt)
+  EvScope(nbmf_ctx* c_, int kind_, bool count = true, bool attach_ = false)
+      : c(c_), kind(kind_ | (count ? 0 : 0x100)), attach(attach_ && !getenv("NBMF_TIMING_BRACKET")) {
     if (!c->timing) return;
     if (c->ev_used + 2 > c->ev.size()) {
       for (int i = 0; i < 2; ++i) {
@@ -884,10 +902,23 @@ struct EvScope {
     }
     slot = c->ev_used;
     c->ev_used += 2;
-    hipEventRecord(c->ev[slot], c->stream);
+    if (attach) {
+      tl_attach_start = c->ev[slot];
+      tl_attach_stop = c->ev[slot + 1];
+    } else {
+      hipEventRecord(c->ev[slot], c->stream);
+    }
   }
   ~EvScope() {
-    if (slot != (size_t)-1) hipEventRecord(c->ev[slot + 1], c->stream);
+    if (slot == (size_t)-1) return;
+    if (attach) {
+      if (tl_attach_start) {   // (no launch took them: an error path)
+        tl_attach_start = tl_attach_stop = nullptr;
+        c->ev_used = slot;
+      }
+    } else {
+      hipEventRecord(c->ev[slot + 1], c->stream);
+    }
   }
 };
 
@@ -1049,7 +1080,26 @@ int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int cli
   return NBMF_OK;
 }
 
-int enqueue_h_pass(nbmf_ctx* c) {
+// Single GPU, one slice: the sweep that scores iteration t assembles its loss itself (PassFin: no finalize launch).
+bool fin_fusable(const nbmf_ctx* c) { return !is_sharded(c) && c->KS == 1 && !getenv("NBMF_NO_FUSED_FINALIZE"); }
+void fin_fill(nbmf_ctx* c, PassArgs& a, int t, double tol, int strict) {
+  a.fin.on = 1;
+  a.fin.t = t;
+  a.fin.n_ll = c->chunksH * (int)(c->nA / 16 / wg_strips(c));
+  a.fin.n_prior = c->n_prior_src;
+  a.fin.ll_pad = ll_pad_of(c, strict);
+  a.fin.am1 = c->alpha - 1.0;
+  a.fin.bm1 = c->beta - 1.0;
+  a.fin.n_obs = c->n_obs_global;
+  a.fin.tol = tol;
+  a.fin.prior = c->prior_src;
+  a.fin.losses = c->losses_d;
+  a.fin.scal = c->scal;
+  a.fin.flags = c->flags;
+}
+
+// fin_t >= 0 (and fin_fusable): also the loss and stop test of iteration fin_t, in the sweep's last workgroup
+int enqueue_h_pass(nbmf_ctx* c, int fin_t = -1, double tol = 0.0) {
   if (c->KS > 1) {
     {
       EvScope ev(c, 0);
@@ -1075,8 +1125,9 @@ int enqueue_h_pass(nbmf_ctx* c) {
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.tiny_eps = c->eps < 1e-70;
+  if (fin_t >= 0) fin_fill(c, a, fin_t, tol, 0);
   {
-    EvScope ev(c, 0);
+    EvScope ev(c, 0, true, /*attach=*/true);
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
   }
   if (int rc = enqueue_exchange_after_sweep(c, a, /*with_products=*/true, /*strict=*/0)) return rc;
@@ -1085,7 +1136,7 @@ int enqueue_h_pass(nbmf_ctx* c) {
 
 // Theta-only sweep (no back-products): the log-likelihood of the current factors at a third of the
 // H-pass's MFMA work; the per-wave partials land in lossbuf exactly as an H-pass leaves them.
-int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0) {
+int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0, int fin_t = -1, double tol = 0.0) {
   if (c->KS > 1) {
     if (int rc = enqueue_a_sweeps_sliced(c, false, strict, clip)) return rc;
     PassArgs a{};
@@ -1110,6 +1161,7 @@ int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0) {
   a.tiny_eps = c->eps < 1e-70;
   a.strict = strict;
   a.clip = clip;
+  if (fin_t >= 0) fin_fill(c, a, fin_t, tol, strict);
   HIPCHK(launch_pass<MODE_L>(c->KB, c->data_kind, a, c->chunksH, c->stream));
   if (int rc = enqueue_exchange_after_sweep(c, a, /*with_products=*/false, strict)) return rc;
   return NBMF_OK;
@@ -1263,7 +1315,7 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   a.eps = c->eps;
   a.tiny_eps = c->eps < 1e-70;
   {
-    EvScope ev(c, 0);
+    EvScope ev(c, 0, true, /*attach=*/c->KS == 1);
     if (c->KS > 1) {
       if (int rc = enqueue_a_sweeps_sliced(c, true, 0, 0)) return rc;
     } else {
@@ -1395,7 +1447,7 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
   a.eps = c->eps;
   a.tiny_eps = c->eps < 1e-70;
   {
-    EvScope ev(c, 0);
+    EvScope ev(c, 0, true, /*attach=*/true);
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, s0));
   }
   if (two_streams) HIPCHK(hipEventRecord(c->evH, s0));
@@ -1496,7 +1548,7 @@ int enqueue_w_step(nbmf_ctx* c, int projection) {
   }
   PassArgs a = w_pass_args(c);
   {
-    EvScope ev(c, 1);
+    EvScope ev(c, 1, true, /*attach=*/true);
     HIPCHK(launch_pass<MODE_W>(c->KB, c->data_kind, a, c->chunksW, c->stream));
   }
   const double* q = c->slabW;
@@ -2054,8 +2106,8 @@ int setup_workspaces(nbmf_ctx* c) {
   }
   if (c->data_kind == DATA_BIN) {
     const long long n_tiles = (long long)(c->mA / 16) * (c->nA / 16);
-    HIPCHK(dmalloc(&c->bitsA, sizeof(unsigned long long) * 8 * (size_t)n_tiles));
-    HIPCHK(dmalloc(&c->bitsB, sizeof(unsigned long long) * 8 * (size_t)n_tiles));
+    HIPCHK(dmalloc(&c->bitsA, sizeof(unsigned long long) * 8 * (size_t)n_tiles + PASS_SLACK));   // (slack: record requests and
+    HIPCHK(dmalloc(&c->bitsB, sizeof(unsigned long long) * 8 * (size_t)n_tiles + PASS_SLACK));   //  prefetches run past the end)
     for (int image = 0; image < 2; ++image) {
       hipLaunchKernelGGL(mask_build_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, c->stream,
                          (const uint32_t*)(image == 0 ? c->dataA : c->dataB), image == 0 ? c->bitsA : c->bitsB, n_tiles);
@@ -2603,6 +2655,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   // latency of the five dependent kernels, not by the host's launch rate -- so it is opt-in
   // (NBMF_USE_GRAPH=1), never used with a communicator or event timing.
   const bool use_graph = getenv("NBMF_USE_GRAPH") && !is_sharded(c) && !c->timing && !progress && max_iter >= 8;
+  const bool fused_fin = fin_fusable(c) && !use_graph;
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   if (use_graph) {
@@ -2635,9 +2688,13 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
         if (int rc = enqueue_iteration_rows(c, it, tol)) return rc;
         continue;
       }
-      if (int rc = enqueue_h_pass(c)) return rc;
-      if (it > 0)
-        if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;
+      if (fused_fin) {
+        if (int rc = enqueue_h_pass(c, it - 1, tol)) return rc;   // (with the loss and stop test of iteration it-1)
+      } else {
+        if (int rc = enqueue_h_pass(c)) return rc;
+        if (it > 0)
+          if (int rc = enqueue_finalize(c, it - 1, tol)) return rc;
+      }
       if (int rc = enqueue_h_update(c)) return rc;
       if (int rc = enqueue_w_step(c, c->projection)) return rc;
     }
@@ -2652,8 +2709,13 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
     }
   }
   if (!host_done) {
-    if (int rc = enqueue_loglik_pass(c, 0)) return rc;            // loss of the last iteration (Theta-only sweep)
-    if (int rc = enqueue_finalize(c, use_graph ? -1 : max_iter - 1, tol)) return rc;
+    // loss of the last iteration (Theta-only sweep)
+    if (fused_fin) {
+      if (int rc = enqueue_loglik_pass(c, 0, 0, max_iter - 1, tol)) return rc;
+    } else {
+      if (int rc = enqueue_loglik_pass(c, 0)) return rc;
+      if (int rc = enqueue_finalize(c, use_graph ? -1 : max_iter - 1, tol)) return rc;
+    }
   }
   int fl[2];
   HIPCHK(hipMemcpyAsync(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));

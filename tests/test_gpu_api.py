@@ -218,6 +218,43 @@ def test_progress_reports_arrive_during_the_run(monkeypatch):
         np.testing.assert_array_equal(np.concatenate([v for _, v in calls]), losses)
 
 
+def test_loss_assembled_by_the_sweeps_last_workgroup_is_the_finalize_launch_bit_for_bit(monkeypatch):
+    """Single GPU, five-kernel path: the loss and stop test of iteration t ride in the H-pass of iteration t+1 (its
+    last workgroup to finish sums the partials in finalize_kernel's fixed order) instead of a launch of their own.
+    Same losses, same stop iteration and same factors as with the separate launch (NBMF_NO_FUSED_FINALIZE=1), for
+    binary and real-valued data, with and without the stop rule, over shapes with 1 ... many workgroups per sweep."""
+    from nbmf_mm_amd import _hip
+    monkeypatch.setenv("NBMF_PERSISTENT", "0")
+    r = np.random.default_rng(11)
+    for (m, n, k), real in [((150, 220, 7), False), ((150, 220, 7), True), ((1500, 900, 20), False), ((40, 3000, 33), False)]:
+        Y = r.random((m, n)) if real else (r.random((m, n)) < 0.3).astype(np.float64)
+        mask = r.random((m, n)) < 0.8
+        W0 = r.uniform(0.1, 0.9, (k, m))
+        W0 /= W0.sum(axis=0, keepdims=True)
+        H0 = r.uniform(0.1, 0.9, (k, n))
+        for max_iter, tol in [(40, 0.0), (400, 2e-4)]:
+            out = {}
+            for fused in (True, False):
+                if fused:
+                    monkeypatch.delenv("NBMF_NO_FUSED_FINALIZE", raising=False)
+                else:
+                    monkeypatch.setenv("NBMF_NO_FUSED_FINALIZE", "1")
+                with _hip.Context(m, n, k) as ctx:
+                    ctx.set_hyper(1.2, 1.3)
+                    ctx.upload(Y, mask=mask)
+                    ctx.set_factors(W0, H0)
+                    losses, n_iter = ctx.run(max_iter, tol)
+                    W, H = ctx.get_factors()
+                    ctx.set_factors(W0, H0)            # (a second run on the same context: the ticket counter is back at 0)
+                    again, n_again = ctx.run(max_iter, tol)
+                out[fused] = (losses, n_iter, W, H)
+                np.testing.assert_array_equal(again, losses)
+                assert n_again == n_iter
+            assert out[True][1] == out[False][1] and (tol == 0.0 or 3 < out[True][1] < max_iter)
+            for a, b in zip(out[True], out[False]):
+                np.testing.assert_array_equal(a, b)
+
+
 def test_eps_range_and_log_of_a_negative_number(monkeypatch):
     """eps is a public argument (nbmf_mm_solver(eps=...)): far below the default the binary path's likelihood
     product and its shared reciprocal take their per-entry forms (below 1e-70; 1e-60 and 1e-69 are the last values
