@@ -79,6 +79,9 @@
 #ifndef NBMF_DMA_INTERLEAVE
 #define NBMF_DMA_INTERLEAVE 1   // the waves' LDS-DMA pieces interleaved (4 KiB of consecutive addresses per instant: c3 W-pass 2.15 -> 2.13 ms, H-pass 2.92 -> 2.91) instead of one contiguous run per wave (0)
 #endif
+#ifndef NBMF_ZTRICK
+#define NBMF_ZTRICK 1   // H sweeps of the binary path: |Theta - z| and r z instead of selects (see pass_kernel)
+#endif
 #ifndef NBMF_STAGE_UNROLL
 #define NBMF_STAGE_UNROLL 2   // stages per trip of the sweep loop: with two, the LDS buffer index and the hand-over of the lane-mask registers are static
 #endif
@@ -367,6 +370,7 @@ struct nbmf_ctx {
   double* rowcnt = nullptr;
   double *Wn = nullptr, *WT = nullptr, *WG = nullptr, *Hn = nullptr, *HT = nullptr, *HG = nullptr;
   bool have_factors = false;
+  bool factors_in_range = false;   // W >= 0 with column sums <= 1 + 1e-12, 0 <= H <= 1 - 1e-9 when they were set: Theta stays in [0, 1) for good
   int chunksH = 0, CH_H = 0, chunksW = 0, CH_W = 0;
   int *cstartH = nullptr, *cstartW = nullptr;   // device: chunk boundaries of the two sweeps
   double *slabH = nullptr, *slabW = nullptr, *Pbuf = nullptr, *lossbuf = nullptr, *prior = nullptr, *scal = nullptr;
@@ -980,6 +984,13 @@ inline int wg_strips(const nbmf_ctx* c) { return WG_WAVES * pass_ns(c->KS > 1 ? 
 // exactly log(fl(fl(1-0)+eps)) = log(1+eps) to the likelihood; their total is removed before the loss is
 // assembled (and before any all-reduce).  A strictly masked sweep skips unobserved entries, pads included --
 // except on the general path without a mask, where everything counts as observed.
+// Which variant the sweeps over image A (H-pass, evaluation sweep) take on the binary path: the plain one forms the
+// ratio block of an H sweep from |Theta - z| (pass_kernel, NBMF_ZTRICK), which IS the reference's arithmetic while
+// 0 <= Theta < 1 -- true throughout a fit that starts from factors in range (W on the simplex, H <= 1 - eps stay so) and
+// eps >= 1e-12 (so that 1 - eps is below 1).  Anything else -- H_init above 1, negative entries, a tiny eps -- takes the
+// TINY variant, whose selects follow `_solver.py:42-43` for any Theta.
+int tiny_a(const nbmf_ctx* c) { return c->eps < 1e-70 || (NBMF_ZTRICK && !(c->eps >= 1e-12 && c->factors_in_range)); }
+
 double ll_pad_of(const nbmf_ctx* c, int strict = 0) {
   if (strict && c->data_kind != DATA_F64) return 0.0;
   const double n_pad = (double)c->mA * (double)c->nA - (double)c->m * (double)c->n;
@@ -1065,7 +1076,7 @@ int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int cli
     a.chunk_start = c->cstartH;
     a.C_alloc = c->nA;
     a.eps = c->eps;
-    a.tiny_eps = c->eps < 1e-70;
+    a.tiny_eps = tiny_a(c);
     a.strict = strict;
     a.clip = clip;
     a.theta = c->theta;
@@ -1124,7 +1135,7 @@ int enqueue_h_pass(nbmf_ctx* c, int fin_t = -1, double tol = 0.0) {
   a.chunk_start = c->cstartH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
-  a.tiny_eps = c->eps < 1e-70;
+  a.tiny_eps = tiny_a(c);
   if (fin_t >= 0) fin_fill(c, a, fin_t, tol, 0);
   {
     EvScope ev(c, 0, true, /*attach=*/true);
@@ -1158,7 +1169,7 @@ int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0, int fin_t = -1, d
   a.chunk_start = c->cstartH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
-  a.tiny_eps = c->eps < 1e-70;
+  a.tiny_eps = tiny_a(c);
   a.strict = strict;
   a.clip = clip;
   if (fin_t >= 0) fin_fill(c, a, fin_t, tol, strict);
@@ -1313,7 +1324,7 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   a.chunk_start = c->cstartH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
-  a.tiny_eps = c->eps < 1e-70;
+  a.tiny_eps = tiny_a(c);
   {
     EvScope ev(c, 0, true, /*attach=*/c->KS == 1);
     if (c->KS > 1) {
@@ -1445,7 +1456,7 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
   a.chunk_start = c->cstartH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
-  a.tiny_eps = c->eps < 1e-70;
+  a.tiny_eps = tiny_a(c);
   {
     EvScope ev(c, 0, true, /*attach=*/true);
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, s0));
@@ -2589,7 +2600,18 @@ int nbmf_set_factors(nbmf_ctx* c, const double* W, const double* H) {
   hipLaunchKernelGGL(prior_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Hn, c->prior, c->k, c->KP,
                      (long long)c->n, (long long)c->nA, c->eps);
   HIPCHK(hipGetLastError());
+  // are the factors where a fit keeps them (tiny_a)?  flags[5] collects the violations
+  HIPCHK(hipMemsetAsync(c->flags + 5, 0, sizeof(int), c->stream));
+  {
+    const long long tot = std::max((long long)c->mA, (long long)c->KP * c->nA);
+    hipLaunchKernelGGL(factor_range_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->Wn,
+                       (const double*)c->Hn, c->k, (long long)c->m, (long long)c->mA, (long long)c->n, (long long)c->nA, c->flags + 5);
+    HIPCHK(hipGetLastError());
+  }
+  int out_of_range = 1;
+  HIPCHK(hipMemcpyAsync(&out_of_range, c->flags + 5, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  c->factors_in_range = out_of_range == 0;
   c->prior_src = c->prior;
   c->n_prior_src = c->n_prior_blocks;
   c->have_factors = true;

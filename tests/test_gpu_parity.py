@@ -307,6 +307,41 @@ def test_ragged_shapes_vs_oracle(hip, m, n, k, both_small_paths):
     np.testing.assert_allclose(H, Hr, rtol=0, atol=FACTOR_ATOL)
 
 
+@pytest.mark.parametrize("case", ["H_above_1", "H_exactly_1", "tiny_eps", "W_negative"])
+def test_factors_out_of_the_fits_range_follow_the_reference(hip, case, both_small_paths):
+    """The H sweep's plain variant forms its ratios from |Theta - z|, which is the reference's arithmetic while
+    0 <= Theta < 1 -- what a fit keeps once it starts in range.  Starts that are NOT in range (H_init above or at 1: the
+    reference uses H_init as given, _solver.py:133; an eps so small that 1 - eps is 1; negative entries) are detected
+    when the factors are set and take the variant with the reference's own selects: same losses -- NaNs included,
+    where the reference's log meets a negative number -- and same factors as the oracle."""
+    from nbmf_mm_amd import nbmf_mm_solver
+    r = np.random.default_rng(5)
+    m, n, k = 130, 190, 9
+    Y = (r.random((m, n)) < 0.4).astype(np.float64)
+    mask = r.random((m, n)) < 0.9
+    W0 = r.uniform(0.1, 0.9, (m, k))
+    H0 = r.uniform(0.1, 0.9, (k, n))
+    kw = dict(max_iter=10, tol=0, mask=mask, alpha=1.2, beta=1.3)
+    if case == "H_above_1":
+        H0 = r.uniform(0.1, 1.6, (k, n))
+    elif case == "H_exactly_1":
+        H0[r.random((k, n)) < 0.3] = 1.0
+    elif case == "tiny_eps":
+        kw["eps"] = 1e-30
+    else:
+        W0[r.random((m, k)) < 0.05] *= -0.2
+    with np.errstate(all="ignore"):
+        Wr, Hr, lr, _, _ = orc.solve(Y, k, W_init=W0, H_init=H0, **kw)
+    W, H, l, _, _ = nbmf_mm_solver(Y, k, W_init=W0, H_init=H0, **kw)
+    lr = np.asarray(lr)
+    assert np.array_equal(np.isnan(l), np.isnan(lr))
+    ok = ~np.isnan(lr)
+    np.testing.assert_allclose(np.asarray(l)[ok], lr[ok], rtol=1e-9, atol=0)
+    if np.all(np.isfinite(Wr)) and np.all(np.isfinite(Hr)):
+        np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-8)
+
+
 def test_more_than_128_components(hip):
     """n_components > 128 runs as slices of 128 (Theta kept in memory between the slices' sweeps): every storage
     path, both orientations, the stop rule, transform / score, and the Duchi extension."""
