@@ -156,8 +156,8 @@ int main() {
   }
 
   const int CU = p.multiProcessorCount;
-  // ---- MFMA rate: blocks of 256 threads (1 wave/SIMD) x CU, and 2 blocks per CU
-  for (int bpc = 1; bpc <= 2; ++bpc) {
+  // ---- MFMA rate: blocks of 256 threads (1 wave/SIMD) x CU, 1 to 4 blocks per CU
+  for (int bpc = 1; bpc <= 4; ++bpc) {
     int iters = 2000;
     {
       float ms = time_ms([&] { k_mfma<1><<<CU * bpc, 256>>>(out, iters, 1.0, 0.5); });
@@ -170,6 +170,12 @@ int main() {
       double fl = (double)CU * bpc * 4 * iters * 8 * 4 * 2048.0;
       printf("MFMA f64 16x16x4 nacc=4 blocks/CU=%d : %.2f TFLOP/s  (%.1f cyc/MFMA/SIMD @2.4GHz)\n", bpc, fl / ms / 1e9,
              ms * 1e-3 * 2.4e9 / (iters * 8.0 * 4 * bpc));
+    }
+    {
+      float ms = time_ms([&] { k_mfma<16><<<CU * bpc, 256>>>(out, iters, 1.0, 0.5); });
+      double fl = (double)CU * bpc * 4 * iters * 8 * 16 * 2048.0;
+      printf("MFMA f64 16x16x4 nacc=16 blocks/CU=%d : %.2f TFLOP/s  (%.1f cyc/MFMA/SIMD @2.4GHz)\n", bpc, fl / ms / 1e9,
+             ms * 1e-3 * 2.4e9 / (iters * 8.0 * 16 * bpc));
     }
   }
   // ---- VALU rates, 8 waves/SIMD-ish occupancy: 8 blocks of 256 per CU
