@@ -370,6 +370,7 @@ struct nbmf_ctx {
   double* rowcnt = nullptr;
   double *Wn = nullptr, *WT = nullptr, *WG = nullptr, *Hn = nullptr, *HT = nullptr, *HG = nullptr;
   bool have_factors = false;
+  bool w_free = false;             // inside nbmf_w_only_steps (the W sweeps' variant, w_pass_args)
   bool factors_in_range = false;   // W >= 0 with column sums <= 1 + 1e-12, 0 <= H <= 1 - 1e-9 when they were set: Theta stays in [0, 1) for good
   int chunksH = 0, CH_H = 0, chunksW = 0, CH_W = 0;
   int *cstartH = nullptr, *cstartW = nullptr;   // device: chunk boundaries of the two sweeps
@@ -1242,7 +1243,7 @@ PassArgs w_pass_args(nbmf_ctx* c) {
   a.chunk_start = c->cstartW;
   a.C_alloc = c->mA;
   a.eps = c->eps;
-  a.tiny_eps = c->eps < 1e-70;
+  a.tiny_eps = tiny_a(c) || c->w_free;   // (transform's W steps start from a W that is not on the simplex: the select variant)
   return a;
 }
 
@@ -2795,6 +2796,11 @@ int nbmf_w_only_steps(nbmf_ctx* c, int n_steps) {
   if (n_steps < 0) return fail(NBMF_ERR_ARG, "n_steps must be >= 0");
   if (int rc = set_device(c)) return rc;
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
+  struct FreeW {
+    nbmf_ctx* c;
+    ~FreeW() { c->w_free = false; }
+  } free_w{c};
+  c->w_free = true;   // (W starts off the simplex, _base.py:175: Theta above 1 is possible)
   for (int s = 0; s < n_steps; ++s)
     if (int rc = enqueue_w_step(c, NBMF_PROJ_NORMALIZE)) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
