@@ -851,7 +851,7 @@ int resident_per_cu(int KB, int data_kind) {
 // Measured at c3 / K=64: 768 workgroups = exactly one round of the 768 resident slots is SLOWER (3.23 ms)
 // than 2048 (3.15 ms); anything from 1536 to 4608 is within 1 %.  `slots` is kept for diagnostics.
 // NBMF_TARGET_WGS=<n> overrides the target (tuning experiments only).
-void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int* chunks, int* CH) {
+void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int cus, int* chunks, int* CH) {
   (void)slots;
   int target = 2048;
   if (const char* e = getenv("NBMF_TARGET_WGS")) target = std::max(1, atoi(e));
@@ -868,6 +868,38 @@ void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int* chun
   if (const char* e = getenv("NBMF_MIN_BLOCKS")) min_blocks = std::max(NB, atoi(e));   // (tuning experiments only)
   ch = std::max(ch, std::min(Rb, min_blocks));
   ch = (int)round_up(ch, NB);
+  // The last round.  Workgroups of a sweep are equally long, so they finish in rounds; a CU is as fast with two
+  // resident workgroups as with three (the MFMA pipe is full either way), but a last round that leaves CUs EMPTY is
+  // lost time: 266 strip groups x 8 chunks = 2128 workgroups on 512 such places (configs[4]'s W-pass, K = 128) are
+  // 4.16 rounds -- a fifth round for 80 workgroups, MFMA-busy 84 %.  More chunks are tried (up to four times as many,
+  // whole multiples of 8 first: the XCD renumbering of pass_kernel wants those) until the rounds are >= 95 % full.
+  // The sweeps of configs[1..3] and of their shards already are (2048 or 1024 workgroups: 4 or 2 full rounds).
+  if (cus > 0 && !getenv("NBMF_TARGET_WGS") && !getenv("NBMF_MIN_BLOCKS") && !getenv("NBMF_NO_ROUND_FILL")) {
+    const long long places = (long long)cus * std::min(std::max(slots / cus, 1), 2);
+    auto fill = [&](int blocks_per_chunk) {   // how full the rounds are with chunks of that many row blocks
+      const long long wgs = (long long)strips_groups * ((Rb + blocks_per_chunk - 1) / blocks_per_chunk);
+      return (double)wgs / (double)(((wgs + places - 1) / places) * places);
+    };
+    const int base = (Rb + ch - 1) / ch;   // chunks so far
+    if ((long long)strips_groups * base > places && fill(ch) < 0.95) {
+      int best = ch;
+      double best_fill = fill(ch);
+      for (int pass = 0; pass < 2 && best_fill < 0.95; ++pass) {   // pass 0: whole multiples of 8 chunks only
+        for (int n = base + 1; n <= 4 * base; ++n) {
+          if (pass == 0 && (n & 7)) continue;
+          const int cand = (int)round_up((Rb + n - 1) / n, NB);
+          if (cand < std::min(Rb, min_blocks)) break;
+          const double f = fill(cand);
+          if (f > best_fill + 1e-9) {
+            best_fill = f;
+            best = cand;
+            if (f >= 0.95) break;
+          }
+        }
+      }
+      ch = best;
+    }
+  }
   *CH = ch;
   *chunks = (Rb + ch - 1) / ch;
 }
@@ -2089,8 +2121,8 @@ int setup_workspaces(nbmf_ctx* c) {
   const int slotsH = cus * resident_per_cu<MODE_H>(c->KB, c->data_kind);
   const int slotsW = cus * resident_per_cu<MODE_W>(c->KB, c->data_kind);
   const int ns = wg_strips(c) / WG_WAVES;
-  pick_chunks((int)(c->nA / 16 / wg_strips(c)), (int)(c->mA / 16), NB, slotsH, ns, &c->chunksH, &c->CH_H);
-  pick_chunks((int)(c->mA / 16 / wg_strips(c)), (int)(c->nA / 16), NB, slotsW, ns, &c->chunksW, &c->CH_W);
+  pick_chunks((int)(c->nA / 16 / wg_strips(c)), (int)(c->mA / 16), NB, slotsH, ns, cus, &c->chunksH, &c->CH_H);
+  pick_chunks((int)(c->mA / 16 / wg_strips(c)), (int)(c->nA / 16), NB, slotsW, ns, cus, &c->chunksW, &c->CH_W);
   const std::vector<int> bH = chunk_boundaries((int)(c->mA / 16), c->CH_H);
   const std::vector<int> bW = chunk_boundaries((int)(c->nA / 16), c->CH_W);
   c->chunksH = (int)bH.size() - 1;
