@@ -866,6 +866,7 @@ void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int cus, 
   // (ns = strips per wave: a workgroup of the two-strip kernels does a 64-block sweep's work in 32 blocks)
   int min_blocks = (long long)strips_groups * ns * ((Rb + 63) / 64) >= 512 ? 64 / ns : 8;
   if (const char* e = getenv("NBMF_MIN_BLOCKS")) min_blocks = std::max(NB, atoi(e));   // (tuning experiments only)
+  const bool clipped = ch < std::min(Rb, min_blocks);   // the sweep is too short for the target at min_blocks per chunk
   ch = std::max(ch, std::min(Rb, min_blocks));
   ch = (int)round_up(ch, NB);
   // The last round.  Workgroups of a sweep are equally long, so they finish in rounds; a CU is as fast with two
@@ -880,7 +881,17 @@ void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int cus, 
       const long long wgs = (long long)strips_groups * ((Rb + blocks_per_chunk - 1) / blocks_per_chunk);
       return (double)wgs / (double)(((wgs + places - 1) / places) * places);
     };
-    const int base = (Rb + ch - 1) / ch;   // chunks so far
+    int base = (Rb + ch - 1) / ch;   // chunks so far
+    // (short sweeps at K >= 64, where two workgroups per CU fill the MFMA pipe: ONE round of exactly that many beats two
+    //  rounds of half-length workgroups -- the 8192-row shard of configs[2], 128 strip groups x 512 row blocks: 4 chunks
+    //  1 443 it/s, 8 chunks 1 422; at K = 32, which wants four waves per SIMD, and for the long sweeps of configs[2]
+    //  itself it is the other way round, by 1 %)
+    if (clipped && NB <= 2 && places % strips_groups == 0 && places / strips_groups < base &&
+        (Rb + (int)(places / strips_groups) - 1) / (int)(places / strips_groups) >= min_blocks) {
+      const int n1 = (int)(places / strips_groups);
+      ch = (int)round_up((Rb + n1 - 1) / n1, NB);
+      base = (Rb + ch - 1) / ch;
+    }
     if ((long long)strips_groups * base > places && fill(ch) < 0.95) {
       int best = ch;
       double best_fill = fill(ch);
