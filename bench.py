@@ -197,8 +197,8 @@ def launch_ranks(n, per_process=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--M", type=int, default=65536)
     ap.add_argument("--N", type=int, default=8192)
     ap.add_argument("--K", type=int, default=64)
