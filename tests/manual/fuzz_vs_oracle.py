@@ -15,61 +15,67 @@ import numpy as np
 from nbmf_mm_amd import nbmf_mm_solver
 from oracle import nbmf_oracle as orc
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-r = np.random.default_rng(seed)
-bad = 0
-t0 = time.time()
-for case in range(cases):
-    m = int(r.integers(1, 700))
-    n = int(r.integers(1, 700))
-    k = int(r.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 129, 140]))
-    real = r.random() < 0.25
-    Y = r.random((m, n)) if real else (r.random((m, n)) < r.uniform(0.05, 0.9)).astype(np.float64)
-    mk = r.choice(["none", "bool", "weights"], p=[0.4, 0.45, 0.15])
-    mask = None if mk == "none" else ((r.random((m, n)) < r.uniform(0.3, 0.99)) if mk == "bool" else r.random((m, n)))
-    kw = dict(max_iter=int(r.integers(1, 25)), tol=0, mask=mask, alpha=float(r.uniform(1.0, 2.0)), beta=float(r.uniform(1.0, 2.0)),
-              orientation=str(r.choice(["beta-dir", "dir-beta"])))
-    eps_kind = r.choice(["default", "small", "tiny"], p=[0.8, 0.1, 0.1])
-    if eps_kind == "small":
-        kw["eps"] = 1e-20
-    elif eps_kind == "tiny":
-        kw["eps"] = 1e-80
-    init = r.choice(["seed", "in_range", "H_high", "W_free"], p=[0.4, 0.3, 0.15, 0.15])
-    if init == "seed":
-        kw["random_state"] = int(r.integers(0, 1000))
-    else:
-        # (custom inits are given in the orientation's own shapes: W (m, k), H (k, n))
-        W0 = r.uniform(0.05, 0.95, (m, k))
-        H0 = r.uniform(0.05, 0.95, (k, n))
-        if init == "H_high":
-            (H0 if kw["orientation"] == "beta-dir" else W0)[...] = r.uniform(0.05, 1.5, (k, n) if kw["orientation"] == "beta-dir" else (m, k))
-        if init == "W_free":
-            W0 *= 3.0
-        kw["W_init"], kw["H_init"] = W0, H0
-    os.environ["NBMF_PERSISTENT"] = str(r.choice(["0", "1"]))
-    duchi = bool(r.random() < 0.25) and init in ("seed", "in_range")   # (the extension: Euclidean projection, README.md:27-35)
-    with np.errstate(all="ignore"):
-        Wr, Hr, lr, _, _ = orc.solve(Y, k, step=orc.mm_step_duchi if duchi else None, **kw)
-    try:
-        W, H, l, _, _ = nbmf_mm_solver(Y, k, projection="duchi" if duchi else "normalize", **kw)
-    except Exception as e:   # noqa: BLE001
-        bad += 1
-        print(f"case {case}: EXCEPTION {e!r}  m={m} n={n} k={k} real={real} mask={mk} init={init} eps={eps_kind} {kw['orientation']}")
-        continue
-    lr = np.asarray(lr)
-    l = np.asarray(l)
-    ok = np.array_equal(np.isnan(l), np.isnan(lr))
-    fin = ~np.isnan(lr)
-    if ok and fin.any():
-        ok = np.allclose(l[fin], lr[fin], rtol=1e-9, atol=0)
-    if ok and np.all(np.isfinite(Wr)) and np.all(np.isfinite(Hr)) and fin.all():
-        ok = np.allclose(W, Wr, rtol=0, atol=1e-8) and np.allclose(H, Hr, rtol=0, atol=1e-8)
-    if not ok:
-        bad += 1
-        dl = np.max(np.abs(l[fin] / lr[fin] - 1)) if fin.any() else float("nan")
-        dW = np.max(np.abs(W - Wr)) if np.all(np.isfinite(Wr)) else float("nan")
-        print(f"case {case}: MISMATCH rel loss {dl:.2e} max|dW| {dW:.2e}  m={m} n={n} k={k} real={real} mask={mk} init={init} eps={eps_kind} "
-              f"{kw['orientation']} its={kw['max_iter']} engine={os.environ['NBMF_PERSISTENT']} duchi={duchi}", flush=True)
-print(f"{cases} cases, {bad} failures, {time.time() - t0:.0f} s")
-sys.exit(1 if bad else 0)
+def run(cases, seed, max_dim=700):
+    """Returns the number of failing cases (each printed)."""
+    r = np.random.default_rng(seed)
+    bad = 0
+    t0 = time.time()
+    for case in range(cases):
+        m = int(r.integers(1, max_dim))
+        n = int(r.integers(1, max_dim))
+        k = int(r.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 129, 140]))
+        real = r.random() < 0.25
+        Y = r.random((m, n)) if real else (r.random((m, n)) < r.uniform(0.05, 0.9)).astype(np.float64)
+        mk = r.choice(["none", "bool", "weights"], p=[0.4, 0.45, 0.15])
+        mask = None if mk == "none" else ((r.random((m, n)) < r.uniform(0.3, 0.99)) if mk == "bool" else r.random((m, n)))
+        kw = dict(max_iter=int(r.integers(1, 25)), tol=0, mask=mask, alpha=float(r.uniform(1.0, 2.0)), beta=float(r.uniform(1.0, 2.0)),
+                  orientation=str(r.choice(["beta-dir", "dir-beta"])))
+        eps_kind = r.choice(["default", "small", "tiny"], p=[0.8, 0.1, 0.1])
+        if eps_kind == "small":
+            kw["eps"] = 1e-20
+        elif eps_kind == "tiny":
+            kw["eps"] = 1e-80
+        init = r.choice(["seed", "in_range", "H_high", "W_free"], p=[0.4, 0.3, 0.15, 0.15])
+        if init == "seed":
+            kw["random_state"] = int(r.integers(0, 1000))
+        else:
+            # (custom inits are given in the orientation's own shapes: W (m, k), H (k, n))
+            W0 = r.uniform(0.05, 0.95, (m, k))
+            H0 = r.uniform(0.05, 0.95, (k, n))
+            if init == "H_high":
+                (H0 if kw["orientation"] == "beta-dir" else W0)[...] = r.uniform(0.05, 1.5, (k, n) if kw["orientation"] == "beta-dir" else (m, k))
+            if init == "W_free":
+                W0 *= 3.0
+            kw["W_init"], kw["H_init"] = W0, H0
+        os.environ["NBMF_PERSISTENT"] = str(r.choice(["0", "1"]))
+        duchi = bool(r.random() < 0.25) and init in ("seed", "in_range")   # (the extension: Euclidean projection, README.md:27-35)
+        with np.errstate(all="ignore"):
+            Wr, Hr, lr, _, _ = orc.solve(Y, k, step=orc.mm_step_duchi if duchi else None, **kw)
+        try:
+            W, H, l, _, _ = nbmf_mm_solver(Y, k, projection="duchi" if duchi else "normalize", **kw)
+        except Exception as e:   # noqa: BLE001
+            bad += 1
+            print(f"case {case}: EXCEPTION {e!r}  m={m} n={n} k={k} real={real} mask={mk} init={init} eps={eps_kind} {kw['orientation']}")
+            continue
+        lr = np.asarray(lr)
+        l = np.asarray(l)
+        ok = np.array_equal(np.isnan(l), np.isnan(lr))
+        fin = ~np.isnan(lr)
+        if ok and fin.any():
+            ok = np.allclose(l[fin], lr[fin], rtol=1e-9, atol=0)
+        if ok and np.all(np.isfinite(Wr)) and np.all(np.isfinite(Hr)) and fin.all():
+            ok = np.allclose(W, Wr, rtol=0, atol=1e-8) and np.allclose(H, Hr, rtol=0, atol=1e-8)
+        if not ok:
+            bad += 1
+            dl = np.max(np.abs(l[fin] / lr[fin] - 1)) if fin.any() else float("nan")
+            dW = np.max(np.abs(W - Wr)) if np.all(np.isfinite(Wr)) else float("nan")
+            print(f"case {case}: MISMATCH rel loss {dl:.2e} max|dW| {dW:.2e}  m={m} n={n} k={k} real={real} mask={mk} init={init} eps={eps_kind} "
+                  f"{kw['orientation']} its={kw['max_iter']} engine={os.environ['NBMF_PERSISTENT']} duchi={duchi}", flush=True)
+    return bad, time.time() - t0
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    n_bad, secs = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print(f"{n_cases} cases, {n_bad} failures, {secs:.0f} s")
+    sys.exit(1 if n_bad else 0)
