@@ -202,6 +202,8 @@ def main():
     ap.add_argument("--M", type=int, default=65536)
     ap.add_argument("--N", type=int, default=8192)
     ap.add_argument("--K", type=int, default=64)
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="time the sweeps of every n-th iteration only (0 = chosen from the warm-up's step time: 1 at >= 3 ms)")
     ap.add_argument("--no-mask", action="store_true")
     ap.add_argument("--projection", default="duchi", choices=["normalize", "duchi"])
     ap.add_argument("--seed", type=int, default=0)
@@ -347,9 +349,20 @@ def run_rank(args, rank, local_rank, world):
         sync()
         return group.max_float(dt), losses
 
+    event_stride = 1
     if args.warmup > 0:
+        tw0 = time.perf_counter()
         ctx.run(args.warmup, 0.0)
-    ctx.timing_enable(not args.no_events)
+        ctx.synchronize()
+        warm_ms = 1e3 * (time.perf_counter() - tw0) / args.warmup
+        # a timed dispatch costs ~2.5 us: where an iteration is short, the events ride on a sample of the timed region's
+        # sweeps (every 4th iteration below 1.5 ms per step, every 2nd below 3 ms) -- roofline.timed_launches says how many
+        if args.event_stride > 0:
+            event_stride = args.event_stride
+        elif args.steps >= 16:
+            event_stride = 4 if warm_ms < 1.5 else (2 if warm_ms < 3.0 else 1)
+        event_stride = int(group.max_float(float(event_stride)))
+    ctx.timing_enable(False if args.no_events else event_stride)
     dt, losses = timed(args.steps)
     tim = ctx.timing()
     ctx.timing_enable(False)
@@ -440,7 +453,7 @@ def run_rank(args, rank, local_rank, world):
                                          "%.3g; beyond that every launch reads the factor panels, once per XCD and chunk pair while they fit "
                                          "the L2s: DESIGN.md 4.1, 5)" % (m_loc * N * (0.25 if binary_path else (16 if args.storage == "f64w" else 8))
                                                                         + 2.0 * 16 * K * N * 8),
-                         "hpass_ms": h_ms, "wpass_ms": w_ms,
+                         "hpass_ms": h_ms, "wpass_ms": w_ms, "timed_launches": int(tim["hpass_launches"]), "event_stride": event_stride,
                          # the whole iteration against the same peak, two ways: EXECUTED MFMA flop (the W-pass runs one
                          # back-product instead of two, SURVEY N4: 6 + 4 = 10*m*N*K) -- the utilisation figure -- and the
                          # reference's ALGORITHMIC 12*m*N*K, which credits work that is not executed

@@ -227,7 +227,9 @@ int nbmf_set_peer_timeout_ms(nbmf_ctx* ctx, double ms);
  * shard again and another nbmf_comm_init* may follow.  Collective in effect: every rank must do the same. */
 int nbmf_comm_detach(nbmf_ctx* ctx);
 
-/* Measurement: HIP-event timing of the two fused pass kernels on the context's stream. */
+/* Measurement: HIP-event timing of the two fused pass kernels on the context's stream.  enable: 0 = off, 1 = every
+ * sweep, n > 1 = the sweeps of every n-th iteration of a run (a timed dispatch costs ~2.5 us: at sub-millisecond
+ * iterations a sample of the launches keeps the measurement from slowing what it measures). */
 int nbmf_timing_enable(nbmf_ctx* ctx, int enable);
 /* ms summed over launches since enable, and launch counts; any pointer may be NULL. */
 int nbmf_timing_get(nbmf_ctx* ctx, double* hpass_ms, int* hpass_launches, double* wpass_ms, int* wpass_launches);

@@ -381,7 +381,8 @@ class Context:
         self._host_cb = None
 
     def timing_enable(self, on=True):
-        _check(self._lib.nbmf_timing_enable(self._h, int(bool(on))))
+        """on: False / True, or an int n > 1 for the sweeps of every n-th iteration only."""
+        _check(self._lib.nbmf_timing_enable(self._h, int(on) if not isinstance(on, bool) else int(on)))
 
     def timing(self):
         hm, wm, hn, wn = c_double(0), c_double(0), c_int(0), c_int(0)

@@ -456,6 +456,8 @@ struct nbmf_ctx {
   int progress_every = 0;
   // timing
   bool timing = false;
+  int timing_stride = 1;   // events on the sweeps of every timing_stride-th iteration of a run (nbmf_timing_enable)
+  int timing_it = 0;       // the iteration being enqueued
   std::vector<hipEvent_t> ev;   // pairs
   std::vector<int> ev_kind;     // 0 = H-pass, 1 = W-pass
   size_t ev_used = 0;
@@ -937,7 +939,7 @@ struct EvScope {
   // attach = true: the scope holds exactly one pass launch, on c->stream, which carries the events itself (launch_pass_tt)
   EvScope(nbmf_ctx* c_, int kind_, bool count = true, bool attach_ = false)
       : c(c_), kind(kind_ | (count ? 0 : 0x100)), attach(attach_ && !getenv("NBMF_TIMING_BRACKET")) {
-    if (!c->timing) return;
+    if (!c->timing || (c->timing_stride > 1 && c->timing_it % c->timing_stride != 0)) return;
     if (c->ev_used + 2 > c->ev.size()) {
       for (int i = 0; i < 2; ++i) {
         hipEvent_t e;
@@ -2746,6 +2748,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   while (it < max_iter && !host_done) {
     const int end = std::min(max_iter, it + batch);
     for (; it < end; ++it) {
+      c->timing_it = it;
       if (use_graph) {
         HIPCHK(hipGraphLaunch(gexec, c->stream));
         continue;
@@ -3180,6 +3183,8 @@ int nbmf_comm_init_peer(nbmf_ctx* c, const void* handles, int nranks, int rank, 
 int nbmf_timing_enable(nbmf_ctx* c, int enable) {
   if (!c) return fail(NBMF_ERR_ARG, "null context");
   c->timing = enable != 0;
+  c->timing_stride = enable > 1 ? enable : 1;
+  c->timing_it = 0;
   c->ev_used = 0;
   c->t_ms[0] = c->t_ms[1] = 0;
   c->t_n[0] = c->t_n[1] = 0;
