@@ -79,6 +79,12 @@
 #ifndef NBMF_DMA_INTERLEAVE
 #define NBMF_DMA_INTERLEAVE 1   // the waves' LDS-DMA pieces interleaved (4 KiB of consecutive addresses per instant: c3 W-pass 2.15 -> 2.13 ms, H-pass 2.92 -> 2.91) instead of one contiguous run per wave (0)
 #endif
+#ifndef NBMF_DIV_RESIDUAL
+#define NBMF_DIV_RESIDUAL 0   // general path: 1 = quotients with a residual correction step (div_nr)
+#endif
+#ifndef NBMF_GENERAL_BATCH4
+#define NBMF_GENERAL_BATCH4 (NBMF_BATCH_RCP && !NBMF_IEEE_DIV && !NBMF_DIV_RESIDUAL)   // general path: one reciprocal per lane and tile (see pass_kernel)
+#endif
 #ifndef NBMF_ZTRICK
 #define NBMF_ZTRICK 1   // H sweeps of the binary path: |Theta - z| and r z instead of selects (see pass_kernel)
 #endif
