@@ -79,6 +79,9 @@
 #ifndef NBMF_DMA_INTERLEAVE
 #define NBMF_DMA_INTERLEAVE 1   // the waves' LDS-DMA pieces interleaved (4 KiB of consecutive addresses per instant: c3 W-pass 2.15 -> 2.13 ms, H-pass 2.92 -> 2.91) instead of one contiguous run per wave (0)
 #endif
+#ifndef NBMF_SETPRIO
+#define NBMF_SETPRIO 3   // wave priorities by phase: 3 = vector phase first where it pays (see pass_kernel), 2 = everywhere, 1 = MFMA phases first, 0 = off
+#endif
 #ifndef NBMF_DIV_RESIDUAL
 #define NBMF_DIV_RESIDUAL 0   // general path: 1 = quotients with a residual correction step (div_nr)
 #endif
