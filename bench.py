@@ -27,8 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet fp64 matrix = 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
-PEAK_MEASURED_TFLOPS = 72.0    # a loop of nothing but v_mfma_f64_16x16x4_f64 on all 1024 SIMDs, best of 1-4 waves per SIMD x 1/4/16 independent
-                               # accumulators: one MFMA per ~70 cycles, not 64 (tools/microbench.hip, profiles/r3_f64_mfma_issue_rate_and_clock.txt)
+PEAK_MEASURED_TFLOPS = 77.8    # a loop of nothing but v_mfma_f64_16x16x4_f64 with VGPR accumulators on all 1024 SIMDs, sustained over 85 ms
+                               # launches: 64.6 cycles per MFMA (tools/microbench3.hip, profiles/r3_f64_mfma_issue_rate_and_clock.txt;
+                               # the bare loop of tools/microbench.hip, AGPR accumulators, measures 72.0)
 
 
 def make_shard(M, N, r0, r1, seed, density=0.25, observed=0.9, masked=True):
