@@ -255,6 +255,44 @@ def test_loss_assembled_by_the_sweeps_last_workgroup_is_the_finalize_launch_bit_
                 np.testing.assert_array_equal(a, b)
 
 
+def test_sweep_timing_counts_launches_in_both_forms_and_with_a_stride(monkeypatch):
+    """nbmf_timing_enable: the events of a sweep that is one launch ride in its own dispatch packet
+    (NBMF_TIMING_BRACKET=1: recorded around it); either way every sweep is counted once, its time is positive and of the
+    same size, the run's results do not depend on timing, and enable = n > 1 times the sweeps of every n-th iteration."""
+    from nbmf_mm_amd import _hip
+    monkeypatch.setenv("NBMF_PERSISTENT", "0")
+    r = np.random.default_rng(21)
+    m, n, k = 900, 1100, 24
+    Y = (r.random((m, n)) < 0.3).astype(np.float64)
+    W0 = r.uniform(0.1, 0.9, (k, m))
+    W0 /= W0.sum(axis=0, keepdims=True)
+    H0 = r.uniform(0.1, 0.9, (k, n))
+    out = {}
+    for form in ("plain", "attached", "bracket", "stride4"):
+        if form == "bracket":
+            monkeypatch.setenv("NBMF_TIMING_BRACKET", "1")
+        else:
+            monkeypatch.delenv("NBMF_TIMING_BRACKET", raising=False)
+        with _hip.Context(m, n, k) as ctx:
+            ctx.set_hyper(1.2, 1.2)
+            ctx.upload(Y)
+            ctx.set_factors(W0, H0)
+            if form != "plain":
+                ctx.timing_enable(4 if form == "stride4" else True)
+            losses, n_iter = ctx.run(20, 0.0)
+            t = ctx.timing() if form != "plain" else None
+            out[form] = (losses, ctx.get_factors(), t)
+    for form in ("attached", "bracket", "stride4"):
+        np.testing.assert_array_equal(out[form][0], out["plain"][0])
+        np.testing.assert_array_equal(out[form][1][0], out["plain"][1][0])
+        t = out[form][2]
+        want = 5 if form == "stride4" else 20
+        assert t["hpass_launches"] == want and t["wpass_launches"] == want
+        assert 0.0 < t["hpass_ms"] / want < 5.0 and 0.0 < t["wpass_ms"] / want < 5.0
+    ta, tb = out["attached"][2], out["bracket"][2]
+    assert 0.5 < ta["hpass_ms"] / tb["hpass_ms"] < 2.0 and 0.5 < ta["wpass_ms"] / tb["wpass_ms"] < 2.0
+
+
 def test_eps_range_and_log_of_a_negative_number(monkeypatch):
     """eps is a public argument (nbmf_mm_solver(eps=...)): far below the default the binary path's likelihood
     product and its shared reciprocal take their per-entry forms (below 1e-70; 1e-60 and 1e-69 are the last values
