@@ -137,6 +137,10 @@ int nbmf_run_batch(nbmf_ctx* ctx, int n_problems, const double* alpha, const dou
                    int max_iter, double tol, double* losses, int* n_iter, double* W_out, double* H_out);
 /* Diagnostics: persistent launches nbmf_run_batch made on this context and the problems they served. */
 int nbmf_batch_stats(nbmf_ctx* ctx, int* launches, int* problems);
+/* Diagnostics: how the two sweeps of an iteration are cut (valid after an upload / generate): chunks of the H-pass and of
+ * the W-pass and the row blocks (16 rows of the swept image) per chunk; a sweep launches (column strips / 4) x chunks
+ * workgroups.  Any pointer may be NULL. */
+int nbmf_sweep_info(nbmf_ctx* ctx, int* h_chunks, int* h_blocks_per_chunk, int* w_chunks, int* w_blocks_per_chunk);
 
 /* Progress reports while nbmf_run works (the `verbose` prints of _solver.py:165-166 need the losses as they
  * arrive, not after the run): with a callback set, nbmf_run synchronises after every `every` iterations and

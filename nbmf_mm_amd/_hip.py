@@ -35,7 +35,7 @@ SYMBOLS = [
     "nbmf_comm_init_host", "nbmf_peer_export", "nbmf_comm_init_peer", "nbmf_comm_detach",
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
     "nbmf_set_progress", "nbmf_device_synchronize", "nbmf_small_stats", "nbmf_generate_slice", "nbmf_set_storage",
-    "nbmf_set_exchange_panels", "nbmf_set_peer_timeout_ms", "nbmf_run_batch", "nbmf_batch_stats",
+    "nbmf_set_exchange_panels", "nbmf_set_peer_timeout_ms", "nbmf_run_batch", "nbmf_batch_stats", "nbmf_sweep_info",
 ]
 
 
@@ -123,6 +123,7 @@ def load():
     lib.nbmf_run_batch.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p,
                                    c_void_p, c_void_p]
     lib.nbmf_batch_stats.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
+    lib.nbmf_sweep_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     lib.nbmf_w_only_steps.argtypes = [c_void_p, c_int]
     lib.nbmf_loss.argtypes = [c_void_p, dp]
     lib.nbmf_loglik.argtypes = [c_void_p, c_int, dp]
@@ -309,6 +310,12 @@ class Context:
         a, b = c_int(0), c_int(0)
         _check(self._lib.nbmf_batch_stats(self._h, byref(a), byref(b)))
         return a.value, b.value
+
+    def sweep_info(self):
+        """{"h_chunks", "h_blocks", "w_chunks", "w_blocks"}: how the two sweeps are cut (after an upload / generate)."""
+        v = [c_int(0) for _ in range(4)]
+        _check(self._lib.nbmf_sweep_info(self._h, *[byref(x) for x in v]))
+        return dict(zip(("h_chunks", "h_blocks", "w_chunks", "w_blocks"), (x.value for x in v)))
 
     def w_only_steps(self, n_steps):
         _check(self._lib.nbmf_w_only_steps(self._h, int(n_steps)))

@@ -2846,6 +2846,16 @@ int nbmf_batch_stats(nbmf_ctx* c, int* launches, int* problems) {
   return NBMF_OK;
 }
 
+int nbmf_sweep_info(nbmf_ctx* c, int* h_chunks, int* h_blocks, int* w_chunks, int* w_blocks) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  if (!c->cstartH) return fail(NBMF_ERR_STATE, "no data on the device yet");
+  if (h_chunks) *h_chunks = c->chunksH;
+  if (h_blocks) *h_blocks = c->CH_H;
+  if (w_chunks) *w_chunks = c->chunksW;
+  if (w_blocks) *w_blocks = c->CH_W;
+  return NBMF_OK;
+}
+
 int nbmf_w_only_steps(nbmf_ctx* c, int n_steps) {
   if (int rc = ready(c)) return rc;
   if (n_steps < 0) return fail(NBMF_ERR_ARG, "n_steps must be >= 0");

@@ -396,3 +396,25 @@ def test_config4_whole_on_one_gpu_and_as_eight_ranks_sharing_it():
                 np.testing.assert_array_equal(H_k, ranks[0][tr]["stop"][2])
     # peer and peer2 move the same sums in the same (rank) order: the same bits
     np.testing.assert_array_equal(ranks[0]["peer"]["tol0"][1], ranks[0]["peer2"]["tol0"][1])
+
+
+def test_sweeps_are_cut_so_that_the_last_round_leaves_no_cu_empty():
+    """nbmf_sweep_info: the chunking rules of DESIGN.md 4.1 on the shapes they were measured on -- configs[2] (2048
+    workgroups per sweep: 4 full rounds of two per CU), its 8192-row shard (a short sweep at K = 64: ONE round of 512),
+    configs[1] (K = 32 keeps 1024), and a shape with few strip groups (configs[4]'s W-pass: 266 x 8 = 2128 workgroups
+    would run a fifth round for 80 of them; more chunks, a whole multiple of 8, until the rounds are >= 95 % full)."""
+    from nbmf_mm_amd import _hip
+    def info(m, n, k):
+        with _hip.Context(m, n, k) as ctx:
+            ctx.generate(1, density=0.25, observed=1.0)
+            return ctx.sweep_info()
+    i = info(65536, 8192, 64)
+    assert (i["h_chunks"], i["w_chunks"]) == (16, 2) and i["h_blocks"] == 256 and i["w_blocks"] == 256
+    i = info(8192, 8192, 64)
+    assert (i["h_chunks"], i["w_chunks"]) == (4, 4) and i["h_blocks"] == 128
+    i = info(8192, 8192, 32)
+    assert (i["h_chunks"], i["w_chunks"]) == (8, 8) and i["h_blocks"] == 64
+    i = info(17000, 60000, 128)                      # (configs[4]'s row count; fewer columns keep the test light)
+    groups_w = -(-17000 // 64)
+    wgs = groups_w * i["w_chunks"]
+    assert i["w_chunks"] % 8 == 0 and wgs / (-(-wgs // 512) * 512) >= 0.95
