@@ -449,11 +449,12 @@ def run_rank(args, rank, local_rank, world):
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                          "peak_measured": PEAK_MEASURED_TFLOPS, "frac_of_measured": achieved / PEAK_MEASURED_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_unit": "bytes per launch (PMC: (2*FETCH_SIZE + WRITE_SIZE) KiB; algorithmic: the data image the "
-                                         "sweep reads -- lane-mask records, m*N/4 bytes, on the binary path -- + 2*chunks*K*N*8 slab bytes = "
-                                         "%.3g; beyond that every launch reads the factor panels, once per XCD and chunk pair while they fit "
-                                         "the L2s: DESIGN.md 4.1, 5)" % (m_loc * N * (0.25 if binary_path else (16 if args.storage == "f64w" else 8))
-                                                                        + 2.0 * 16 * K * N * 8),
+                         "traffic_unit": "bytes per launch (PMC: (2*FETCH_SIZE + WRITE_SIZE) KiB; compulsory: the data image the sweep "
+                                         "reads -- lane-mask records, m*N/4 bytes, on the binary path -- + 2*chunks*K*N*8 slab bytes + one "
+                                         "read of the streamed factor's two operand images (2*m*K*8) and of the stationary one (N*K*8) = "
+                                         "%.3g; what a launch reads beyond that is those images again, once per XCD round of a chunk's "
+                                         "workgroups: DESIGN.md 4.1, 5)" % (m_loc * N * (0.25 if binary_path else (16 if args.storage == "f64w" else 8))
+                                                                        + 2.0 * 16 * K * N * 8 + 2.0 * m_loc * K * 8 + N * K * 8.0),
                          "hpass_ms": h_ms, "wpass_ms": w_ms, "timed_launches": int(tim["hpass_launches"]), "event_stride": event_stride,
                          # the whole iteration against the same peak, two ways: EXECUTED MFMA flop (the W-pass runs one
                          # back-product instead of two, SURVEY N4: 6 + 4 = 10*m*N*K) -- the utilisation figure -- and the
