@@ -367,6 +367,7 @@ def run_rank(args, rank, local_rank, world):
     dt, losses = timed(args.steps)
     tim = ctx.timing()
     ctx.timing_enable(False)
+    h_chunks = ctx.sweep_info()["h_chunks"]
     replicas_identical = None
     devices = group.all_gather(dev_index)
     if world > 1:
@@ -454,7 +455,7 @@ def run_rank(args, rank, local_rank, world):
                                          "read of the streamed factor's two operand images (2*m*K*8) and of the stationary one (N*K*8) = "
                                          "%.3g; what a launch reads beyond that is those images again, once per XCD round of a chunk's "
                                          "workgroups: DESIGN.md 4.1, 5)" % (m_loc * N * (0.25 if binary_path else (16 if args.storage == "f64w" else 8))
-                                                                        + 2.0 * 16 * K * N * 8 + 2.0 * m_loc * K * 8 + N * K * 8.0),
+                                                                        + 2.0 * h_chunks * K * N * 8 + 2.0 * m_loc * K * 8 + N * K * 8.0),
                          "hpass_ms": h_ms, "wpass_ms": w_ms, "timed_launches": int(tim["hpass_launches"]), "event_stride": event_stride,
                          # the whole iteration against the same peak, two ways: EXECUTED MFMA flop (the W-pass runs one
                          # back-product instead of two, SURVEY N4: 6 + 4 = 10*m*N*K) -- the utilisation figure -- and the
