@@ -2634,6 +2634,20 @@ int nbmf_get_n_obs(nbmf_ctx* c, double* n_obs) {
   return NBMF_OK;
 }
 
+// Are the factors on the device where a fit keeps them (tiny_a)?  flags[5] collects the violations; synchronises.
+int check_factor_range(nbmf_ctx* c) {
+  HIPCHK(hipMemsetAsync(c->flags + 5, 0, sizeof(int), c->stream));
+  const long long tot = std::max((long long)c->mA, (long long)c->KP * c->nA);
+  hipLaunchKernelGGL(factor_range_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->Wn,
+                     (const double*)c->Hn, c->k, (long long)c->m, (long long)c->mA, (long long)c->n, (long long)c->nA, c->flags + 5);
+  HIPCHK(hipGetLastError());
+  int out_of_range = 1;
+  HIPCHK(hipMemcpyAsync(&out_of_range, c->flags + 5, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->factors_in_range = out_of_range == 0;
+  return NBMF_OK;
+}
+
 int nbmf_set_factors(nbmf_ctx* c, const double* W, const double* H) {
   if (!c || !W || !H) return fail(NBMF_ERR_ARG, "null argument");
   if (int rc = set_device(c)) return rc;
@@ -2655,18 +2669,7 @@ int nbmf_set_factors(nbmf_ctx* c, const double* W, const double* H) {
   hipLaunchKernelGGL(prior_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Hn, c->prior, c->k, c->KP,
                      (long long)c->n, (long long)c->nA, c->eps);
   HIPCHK(hipGetLastError());
-  // are the factors where a fit keeps them (tiny_a)?  flags[5] collects the violations
-  HIPCHK(hipMemsetAsync(c->flags + 5, 0, sizeof(int), c->stream));
-  {
-    const long long tot = std::max((long long)c->mA, (long long)c->KP * c->nA);
-    hipLaunchKernelGGL(factor_range_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->Wn,
-                       (const double*)c->Hn, c->k, (long long)c->m, (long long)c->mA, (long long)c->n, (long long)c->nA, c->flags + 5);
-    HIPCHK(hipGetLastError());
-  }
-  int out_of_range = 1;
-  HIPCHK(hipMemcpyAsync(&out_of_range, c->flags + 5, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  c->factors_in_range = out_of_range == 0;
+  if (int rc = check_factor_range(c)) return rc;
   c->prior_src = c->prior;
   c->n_prior_src = c->n_prior_blocks;
   c->have_factors = true;
@@ -2866,8 +2869,15 @@ int nbmf_w_only_steps(nbmf_ctx* c, int n_steps) {
     ~FreeW() { c->w_free = false; }
   } free_w{c};
   c->w_free = true;   // (W starts off the simplex, _base.py:175: Theta above 1 is possible)
-  for (int s = 0; s < n_steps; ++s)
+  for (int s = 0; s < n_steps; ++s) {
     if (int rc = enqueue_w_step(c, NBMF_PROJ_NORMALIZE)) return rc;
+    if (s == 0 && n_steps > 2) {
+      // ... and is on it from the first step on: looked at once (a ~20 us kernel and a synchronisation), so that the
+      // remaining steps can take the sweeps' plain variant if W has come out non-negative as well
+      if (int rc = check_factor_range(c)) return rc;
+      c->w_free = !c->factors_in_range;
+    }
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->timing) timing_collect(c);
   return peer_check(c);
