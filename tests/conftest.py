@@ -8,8 +8,8 @@ try:
     # Load order matters when PyTorch shares the process: its wheel bundles a private ROCm runtime
     # (libhsa-runtime64.so, libamdhip64.so).  RCCL finds the HSA runtime by plain soname, so if torch is
     # imported AFTER the system HIP runtime has been initialised, RCCL picks torch's uninitialised copy
-    # ("no ROCm-capable device").  bench.py imports torch first; the tests do the same.  (The library
-    # itself never imports torch.)
+    # ("no ROCm-capable device").  So the tests import torch first.  (bench.py and the library
+    # never import torch.)
     import torch  # noqa: F401
 except Exception:  # pragma: no cover - torch is only needed by the multi-process tests
     torch = None
