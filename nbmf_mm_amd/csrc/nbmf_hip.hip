@@ -862,7 +862,7 @@ int resident_per_cu(int KB, int data_kind) {
 // Measured at c3 / K=64: 768 workgroups = exactly one round of the 768 resident slots is SLOWER (3.23 ms)
 // than 2048 (3.15 ms); anything from 1536 to 4608 is within 1 %.  `slots` is kept for diagnostics.
 // NBMF_TARGET_WGS=<n> overrides the target (tuning experiments only).
-void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int cus, int* chunks, int* CH) {
+void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int cus, bool one_round_ok, int* chunks, int* CH) {
   (void)slots;
   int target = 2048;
   if (const char* e = getenv("NBMF_TARGET_WGS")) target = std::max(1, atoi(e));
@@ -896,8 +896,9 @@ void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int cus, 
     // (short sweeps at K >= 64, where two workgroups per CU fill the MFMA pipe: ONE round of exactly that many beats two
     //  rounds of half-length workgroups -- the 8192-row shard of configs[2], 128 strip groups x 512 row blocks: 4 chunks
     //  1 443 it/s, 8 chunks 1 422; at K = 32, which wants four waves per SIMD, and for the long sweeps of configs[2]
-    //  itself it is the other way round, by 1 %)
-    if (clipped && NB <= 2 && places % strips_groups == 0 && places / strips_groups < base &&
+    //  itself it is the other way round, by 1 %.  The H sweep only: a row-sharded run may launch its W sweep in two parts,
+    //  one per exchange panel, and half of four chunks would leave one workgroup per CU)
+    if (one_round_ok && clipped && NB <= 2 && places % strips_groups == 0 && places / strips_groups < base &&
         (Rb + (int)(places / strips_groups) - 1) / (int)(places / strips_groups) >= min_blocks) {
       const int n1 = (int)(places / strips_groups);
       ch = (int)round_up((Rb + n1 - 1) / n1, NB);
@@ -2143,8 +2144,8 @@ int setup_workspaces(nbmf_ctx* c) {
   const int slotsH = cus * resident_per_cu<MODE_H>(c->KB, c->data_kind);
   const int slotsW = cus * resident_per_cu<MODE_W>(c->KB, c->data_kind);
   const int ns = wg_strips(c) / WG_WAVES;
-  pick_chunks((int)(c->nA / 16 / wg_strips(c)), (int)(c->mA / 16), NB, slotsH, ns, cus, &c->chunksH, &c->CH_H);
-  pick_chunks((int)(c->mA / 16 / wg_strips(c)), (int)(c->nA / 16), NB, slotsW, ns, cus, &c->chunksW, &c->CH_W);
+  pick_chunks((int)(c->nA / 16 / wg_strips(c)), (int)(c->mA / 16), NB, slotsH, ns, cus, /*one_round_ok=*/true, &c->chunksH, &c->CH_H);
+  pick_chunks((int)(c->mA / 16 / wg_strips(c)), (int)(c->nA / 16), NB, slotsW, ns, cus, /*one_round_ok=*/false, &c->chunksW, &c->CH_W);
   const std::vector<int> bH = chunk_boundaries((int)(c->mA / 16), c->CH_H);
   const std::vector<int> bW = chunk_boundaries((int)(c->nA / 16), c->CH_W);
   c->chunksH = (int)bH.size() - 1;
