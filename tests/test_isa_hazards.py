@@ -56,7 +56,11 @@ def test_the_shipped_library_passes_and_a_seeded_violation_fails_the_build(tmp_p
     build = subprocess.run(["make", "-C", csrc], capture_output=True, text=True)
     assert build.returncode == 0, (build.stdout + build.stderr)[-2000:]
     assert os.path.exists(os.path.join(ROOT, "nbmf_mm_amd", "libnbmf_hip.so"))
-    isa = os.path.join(ROOT, "build", "libnbmf_hip.so.s")
+    # the ISA under its fixed name: left there by whichever build made the library (plain `make`, _hip._autobuild under
+    # a temporary library name), or made now from the same sources and flags
+    mk = subprocess.run(["make", "-C", csrc, "isa"], capture_output=True, text=True)
+    assert mk.returncode == 0, (mk.stdout + mk.stderr)[-2000:]
+    isa = os.path.join(ROOT, "build", "nbmf_hip.isa.s")
     n, bad, sbad = _checker().check(isa, check_sgpr=True, verbose=False)
     assert n > 2000 and (bad, sbad) == (0, 0)
     # the same sources with one deliberately unprotected MFMA compiled in: make must fail and leave no library behind
