@@ -213,25 +213,52 @@ __device__ __forceinline__ double max0(double x) {
   return r;
 }
 constexpr int LOG_TABLE_BYTES = 256 * 16;
-__device__ __forceinline__ void log_table_fill(double2* tab /* LDS, 256 entries; threads 0..255 */) {
-  if (threadIdx.x < 256) {
-    const double c = 1.0 / (0.5 + ((double)threadIdx.x + 0.5) * (1.0 / 512.0));
-    tab[threadIdx.x] = double2{c, -log(c)};
-  }
+// (TB index bits: 8 -> 256 entries and the series to r^5/5; 10 -> 1024 entries, |r| <= 2^-11, and the series to r^4/4 --
+//  the next term is below 2^-57 -- one FMA fewer per logarithm where the table is there for the taking)
+template <int TB>
+__device__ __forceinline__ double2 log_table_entry(int j) {
+  const double c = 1.0 / (0.5 + ((double)j + 0.5) * (1.0 / (double)(2 << TB)));
+  return double2{c, -log(c)};
 }
-template <bool GUARD>
-__device__ __forceinline__ double log_tab(double x, const double2* tab) {
+__device__ __forceinline__ void log_table_fill(double2* tab /* LDS, 256 entries; threads 0..255 */) {
+  if (threadIdx.x < 256) tab[threadIdx.x] = log_table_entry<8>(threadIdx.x);
+}
+// (LDS_ABS: `tab` is not a pointer but the table's byte address in LDS, known at compile time -- the caller's kernel has
+//  no static LDS, so its dynamic region starts at 0 -- and becomes the gather's immediate offset; through a pointer
+//  derived from the dynamic region's symbol hipcc spends a vector add per gather on a base it cannot fold)
+template <bool GUARD, int TB = 8, bool LDS_ABS = false, typename TAB = const double2*>
+__device__ __forceinline__ double log_tab(double x, TAB tab, double c3 = 0.33333333333333331483, double c4 = -0.25) {
+  static_assert(TB == 8 || TB == 10, "256 or 1024 entries");
   if (GUARD && __builtin_expect(!__builtin_amdgcn_class(x, 0x100), 0)) return log(x);   // not a positive normal number
   const uint32_t hi = (uint32_t)__double2hiint(x);
   const double m = __builtin_amdgcn_frexp_mant(x);   // in [0.5, 1); a NaN stays a NaN and so reaches the result
-  const double2 e = tab[(hi >> 12) & 0xFFu];
+  const uint32_t off = (hi >> (16 - TB)) & (((1u << TB) - 1u) << 4);   // byte offset of the entry: two instructions
+  double2 e;
+  if constexpr (LDS_ABS) {
+    typedef double d2raw __attribute__((ext_vector_type(2)));
+    const d2raw v = *(const __attribute__((address_space(3))) d2raw*)(uintptr_t)(off + (uint32_t)tab);
+    e = double2{v[0], v[1]};
+  } else {
+    e = *(const double2*)((const char*)tab + off);
+  }
   const double r = __builtin_fma(m, e.x, -1.0);
-  double p = __builtin_fma(r, 0.2, -0.25);
-  p = __builtin_fma(r, p, 0.33333333333333331483);
+  double p;
+  if (TB == 8) {
+    p = __builtin_fma(r, 0.2, -0.25);
+    p = __builtin_fma(r, p, c3);
+  } else {
+    p = __builtin_fma(r, c4, c3);   // (callers in a hot loop hand both constants over in registers: two literals do not fit one instruction)
+  }
   p = __builtin_fma(r, p, -0.5);
   p = __builtin_fma(r, p, 1.0);
   const double k = (double)__builtin_amdgcn_frexp_exp(x);
   return __builtin_fma(r, p, __builtin_fma(k, 0.69314718055994530942, e.y));
+}
+// The 1024-entry table, once per device and process in memory (a workgroup of the general path's sweeps copies it
+// into LDS: 16 KiB from L2 instead of 1024 library logarithms).
+__global__ __launch_bounds__(256) void log_table_kernel(double2* tab) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  tab[j] = log_table_entry<10>(j);
 }
 
 // Per-lane selects on a 64-bit wave mask, written out because the pass kernels are VALU-issue bound next to
@@ -759,6 +786,28 @@ void arena_release(ArenaSlot* a) {
     }
 }
 
+// ---- the general path's logarithm table: one copy per device and process ------------------------
+const double2* g_logtab[64] = {nullptr};
+std::mutex g_logtab_mu;
+hipError_t log_table_device(const double2** out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(g_logtab_mu);
+  if (!g_logtab[dev & 63]) {
+    double2* t = nullptr;
+    if ((e = hipMalloc((void**)&t, 1024 * sizeof(double2))) != hipSuccess) return e;
+    hipLaunchKernelGGL(log_table_kernel, dim3(4), dim3(256), 0, 0, t);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {   // (once per process: every stream may read it afterwards)
+      hipFree(t);
+      return e;
+    }
+    g_logtab[dev & 63] = t;
+  }
+  *out = g_logtab[dev & 63];
+  return hipSuccess;
+}
+
 // ---- pass launch ----------------------------------------------------------------------------
 // Timing (nbmf_timing_enable): a sweep that is ONE launch carries its two events in its own dispatch packet
 // (hipExtLaunchKernelGGL: start and end of that kernel, no barrier packets in front of and behind it, which at
@@ -766,11 +815,16 @@ void arena_release(ArenaSlot* a) {
 // takes them.  Sweeps of several launches are bracketed by recorded events as before.
 thread_local hipEvent_t tl_attach_start = nullptr, tl_attach_stop = nullptr;
 template <int KB, int DATA, int MODE, int TH, bool TINY>
-hipError_t launch_pass_tt(const PassArgs& a, int chunks, hipStream_t st) {
-  dim3 grid(a.Cb / (WG_WAVES * pass_ns(KB, DATA)), chunks);
-  constexpr int lds_bytes = ((NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES) + (DATA != DATA_BIN ? LOG_TABLE_BYTES : 0);
+hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
+  dim3 grid(a_.Cb / (WG_WAVES * pass_ns(KB, DATA)), chunks);
+  constexpr int lds_bytes = pass_lds_bytes(KB, DATA, MODE);
   if (lds_bytes > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH, TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  PassArgs a = a_;
+  if (DATA != DATA_BIN && MODE != MODE_W && MODE != MODE_T && pass_log_bits(KB) == 10) {
+    hipError_t e = log_table_device(&a.ltab_g);
     if (e != hipSuccess) return e;
   }
   if (tl_attach_start) {
@@ -785,7 +839,7 @@ hipError_t launch_pass_tt(const PassArgs& a, int chunks, hipStream_t st) {
 // (eps below 1e-70 on the binary path: the variant with per-entry reciprocals and renormalisation, see pass_kernel)
 template <int KB, int DATA, int MODE, int TH = 0>
 hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
-  if (DATA == DATA_BIN && MODE != MODE_T && a.tiny_eps) return launch_pass_tt<KB, DATA, MODE, TH, DATA == DATA_BIN && MODE != MODE_T>(a, chunks, st);
+  if (MODE != MODE_T && a.tiny_eps) return launch_pass_tt<KB, DATA, MODE, TH, MODE != MODE_T>(a, chunks, st);
   return launch_pass_tt<KB, DATA, MODE, TH, false>(a, chunks, st);
 }
 
@@ -851,7 +905,7 @@ template <int MODE>
 int resident_per_cu(int KB, int data_kind) {
   int n = 0;
   const void* f = pass_ptr<MODE>(KB, data_kind);
-  const int lds_bytes = ((NBMF_STAGE_HALF && KB <= 4) ? STAGE_BYTES : 2 * STAGE_BYTES) + (data_kind != DATA_BIN ? LOG_TABLE_BYTES : 0);
+  const int lds_bytes = pass_lds_bytes(KB, data_kind, MODE);
   if (!f || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64 * WG_WAVES, lds_bytes) != hipSuccess || n < 1) n = 2;
   return std::min(n, 8);
 }
@@ -2437,8 +2491,8 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
     HIPCHK(dmalloc(&c->dataB, bytes + PASS_SLACK));
     // (the pack kernel writes every tile of the padded mA x nA grid, pad entries included)
     if (kind == DATA_F64M) {
-      HIPCHK(dmalloc(&c->maskA, bytes));
-      HIPCHK(dmalloc(&c->maskB, bytes));
+      HIPCHK(dmalloc(&c->maskA, bytes + PASS_SLACK));   // (slack: the sweeps request the tile behind their last one)
+      HIPCHK(dmalloc(&c->maskB, bytes + PASS_SLACK));
     }
     HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
 
@@ -3260,13 +3314,15 @@ int nbmf_synchronize(nbmf_ctx* c) {
 }
 
 int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y) {
-  if (!x || !y || n < 1 || op < 0 || op > 5) return fail(NBMF_ERR_ARG, "bad argument");
+  if (!x || !y || n < 1 || op < 0 || op > 6) return fail(NBMF_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(device));
+  const double2* ltab10 = nullptr;
+  HIPCHK(log_table_device(&ltab10));
   double *d = nullptr, *o = nullptr;
   HIPCHK(dmalloc(&d, sizeof(double) * (size_t)n));
   HIPCHK(dmalloc(&o, sizeof(double) * (size_t)n));
   HIPCHK(hipMemcpy(d, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(unary_test_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, d, o, n);
+  hipLaunchKernelGGL(unary_test_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, d, o, n, ltab10);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(y, o, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
   dfree(d);

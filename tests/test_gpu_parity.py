@@ -77,20 +77,23 @@ def test_shared_reciprocal_accuracy(hip):
         assert ulp.max() <= 3.0, (op, ulp.max())
 
 
-def test_log_accuracy(hip):
-    # logarithm of the general path (256-entry table + series): absolute error <= 2.5e-16 + 1 ulp of the result on
-    # (0, 2] -- the loss sums millions of such terms of size ~0.5 -- and the same special values as NumPy elsewhere
+@pytest.mark.parametrize("op", [1, 6], ids=["256-entries-degree-5", "1024-entries-degree-4"])
+def test_log_accuracy(hip, op):
+    # logarithm of the general path (table + series; the product sweeps use the 1024-entry table, whose series is a term
+    # shorter, on t1 / t2 in [1e-8, 1e8]): absolute error <= 2.5e-16 + 1 ulp of the result -- the loss sums millions of
+    # such terms of size ~0.5 -- and the same special values as NumPy elsewhere
     r = np.random.default_rng(1)
     x = np.concatenate([np.exp(r.uniform(np.log(1e-8), np.log(2.0), 1 << 20)), r.uniform(0.5, 1.5, 1 << 18),
+                        np.exp(r.uniform(np.log(1e-8), np.log(1e8), 1 << 20)),
                         1.0 + r.uniform(-1e-6, 1e-6, 1 << 16),
                         [1.0, 1e-8, 1.0 + 1e-8, 0.5, 2.0, np.nextafter(1.0, 0), np.nextafter(1.0, 2), 1e-300, 1e300]])
-    got = hip.selftest_unary(1, x)
+    got = hip.selftest_unary(op, x)
     want = np.log(x)
     err = np.abs(got - want)
     assert (err <= 2.5e-16 + np.spacing(np.abs(want))).all(), (err - np.spacing(np.abs(want))).max()
     with np.errstate(all="ignore"):
         sp = np.array([0.0, -1.0, np.inf, np.nan, 5e-324, -0.0, -np.inf])
-        np.testing.assert_array_equal(hip.selftest_unary(1, sp), np.log(sp))
+        np.testing.assert_array_equal(hip.selftest_unary(op, sp), np.log(sp))
 
 
 def test_one_step_golden_vectors(hip, golden, both_small_paths):
