@@ -75,6 +75,18 @@ int nbmf_set_hyper(nbmf_ctx* ctx, double alpha, double beta, double eps, int pro
 int nbmf_upload(nbmf_ctx* ctx, const double* x, int64_t ldx, int transposed,
                 const void* mask, int mask_kind, int64_t ldmask, int* out_flags);
 
+/* The same upload from a host array of the given element type: NBMF_DATA_F64 (nbmf_upload), or NBMF_DATA_U8 -- uint8 /
+ * bool data, one byte per entry, values 0 and 1 (anything else is out of range: NBMF_ERR_RANGE, the "X must be
+ * binary" of _base.py:90-91).  The reference converts every input to float64 first (check_array(dtype=float64),
+ * _base.py:83; `Y * mask` at _solver.py:30 would do it anyway); a caller that holds its binary matrix as bool or
+ * uint8 hands it over as it is -- BASELINE configs[4]'s 360k x 17k is 6.1 GB that way instead of 49 GB -- and the
+ * pack kernel reads the bytes (nbmf_upload_v(ctx, ptr, dtype{f64,u8}, ld); 7 "Memory at config 5").
+ * ldx in ELEMENTS.  The fit is bit for bit that of the float64 upload of the same values (tested). */
+#define NBMF_DATA_F64 0
+#define NBMF_DATA_U8 1
+int nbmf_upload_v(nbmf_ctx* ctx, const void* x, int x_kind, int64_t ldx, int transposed,
+                  const void* mask, int mask_kind, int64_t ldmask, int* out_flags);
+
 /* Sparse upload of BINARY data: the user's matrix given as a CSR pattern (canonical: sorted or not, but no
  * duplicate entries; every stored entry means 1), optionally with a second CSR pattern of the OBSERVED entries
  * (mask_indptr NULL = everything observed).  Replaces `Y = Y.toarray()` of _solver.py:28-29 / _base.py:86-87
@@ -156,6 +168,13 @@ int nbmf_set_progress(nbmf_ctx* ctx, nbmf_progress_fn fn, void* user, int every)
  * up at a grid barrier and were redone by the five-kernel path.  Environment: NBMF_PERSISTENT=0 switches the
  * single-launch path off. */
 int nbmf_small_stats(nbmf_ctx* ctx, int* runs, int* aborted);
+
+/* Diagnostics, process-wide: fits (nbmf_run calls and problems of nbmf_run_batch) the single-launch engine has served to
+ * the end, persistent launches that gave up (their fits were redone by the launches), and nbmf_run calls the
+ * launch-per-kernel engine has served.  The GPU tests that run every case once per engine read them to make sure the
+ * engine they name is the one that ran (a persistent kernel that silently gave up would otherwise pass as the other).
+ * Any pointer may be NULL. */
+int nbmf_engine_stats(long long* persistent_served, long long* persistent_aborted, long long* launches_served);
 
 /* n_steps repetitions of the simplex-factor update with the Beta factor frozen: the loop body of
  * NBMFMM.transform, _base.py:178-193 (always "normalize", eps as set by nbmf_set_hyper). */
@@ -246,7 +265,7 @@ int nbmf_device_synchronize(int device);
  * caller-supplied values (op 0: Newton reciprocal used on the binary path; op 1: the natural logarithm
  * of the general path; op 2: the general path's quotient, evaluated as (1 - 0.75 x) / x; ops 3, 4: the two quotients
  * of an entry from one shared reciprocal, (1 - 0.75 x) / x and 0.75 x / ((1 - (x - 1e-8)) + 1e-8); op 5: 1/x by the
- * binary path's shared reciprocal of four, groups of four consecutive values) so the host can compare with IEEE 1/x,
+ * binary path's shared reciprocal of four, groups of four consecutive values; op 6: op 1 with the product sweeps' table) so the host can compare with IEEE 1/x,
  * log(x) and the IEEE quotients (accuracy contracts: tests/test_gpu_parity.py). */
 #define NBMF_SELFTEST_RCP 0
 #define NBMF_SELFTEST_LOG 1
@@ -255,6 +274,16 @@ int nbmf_device_synchronize(int device);
 #define NBMF_SELFTEST_DIV_PAIR_B 4
 #define NBMF_SELFTEST_RCP_OF_FOUR 5
 int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y);
+
+#define NBMF_SELFTEST_LOG_1024 6  /* ... with the 1024-entry table of the product sweeps (series to r^4/4) */
+
+/* Measurement helper with no reference counterpart: the f64 matrix rate of `device` as THIS machine delivers it -- a
+ * loop of nothing but v_mfma_f64_16x16x4_f64 (four independent accumulators in VGPRs, two waves on every SIMD), one
+ * launch of about target_ms milliseconds after a warm-up.  bench.py prints it beside the datasheet figure
+ * (roofline.peak_measured; SURVEY 8d asks for the measured peak of the box that ran the bench).  tflops: 2048 flop per
+ * MFMA and wave / time; cycles_per_mfma: SIMD cycles per MFMA at the nominal 2.4 GHz (64 = the datasheet's 78.6 TFLOP/s
+ * on 1024 SIMDs); launch_ms: the timed launch.  Any pointer may be NULL. */
+int nbmf_selftest_mfma_peak(int device, double target_ms, double* tflops, double* cycles_per_mfma, double* launch_ms);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,14 @@ class NBMFMM(BaseEstimator, TransformerMixin):
 
     @staticmethod
     def _validated(X, keep_sparse=False):
+        # _base.py:83 converts every input to float64.  A dense bool / uint8 matrix stays as it is here -- one byte per
+        # entry up to the device, where the pack kernel reads the bytes (nbmf_upload_v): the same fit bit for bit, without
+        # the 8-byte-per-entry host copy (BASELINE configs[4]: 6.1 GB instead of 49 GB).  Shape and dimension checks are
+        # check_array's either way; a uint8 value above 1 is "X must be binary" (:90-91), raised by the device pack.
+        dt = getattr(X, "dtype", None)
+        if dt is not None and not hasattr(X, "toarray") and (dt == np.bool_ or dt == np.uint8):
+            X = check_array(X, dtype=None)
+            return X
         X = check_array(X, accept_sparse="csr", dtype=np.float64)     # _base.py:83
         if hasattr(X, "toarray") and not keep_sparse:
             X = X.toarray()                                            # :86-87
@@ -91,7 +99,7 @@ class NBMFMM(BaseEstimator, TransformerMixin):
             big = False
             raise
         finally:
-            if not big and not sparse and not np.all((X >= 0) & (X <= 1)):
+            if not big and not sparse and X.dtype != np.bool_ and not np.all((X >= 0) & (X <= 1)):
                 raise ValueError("X must be binary") from None
         self.orientation = orientation                                # written back, :95
         n_init = int(self.n_init)

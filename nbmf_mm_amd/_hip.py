@@ -36,7 +36,9 @@ SYMBOLS = [
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
     "nbmf_set_progress", "nbmf_device_synchronize", "nbmf_small_stats", "nbmf_generate_slice", "nbmf_set_storage",
     "nbmf_set_exchange_panels", "nbmf_set_peer_timeout_ms", "nbmf_run_batch", "nbmf_batch_stats", "nbmf_sweep_info",
+    "nbmf_upload_v", "nbmf_selftest_mfma_peak", "nbmf_engine_stats",
 ]
+DATA_F64, DATA_U8 = 0, 1
 
 
 #: int fn(void* user, double* buf, int64 count) -- in-place sum over ranks on a host buffer
@@ -113,6 +115,9 @@ def load():
     lib.nbmf_destroy.argtypes = [c_void_p]
     lib.nbmf_set_hyper.argtypes = [c_void_p, c_double, c_double, c_double, c_int]
     lib.nbmf_upload.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, POINTER(c_int)]
+    lib.nbmf_upload_v.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64, POINTER(c_int)]
+    lib.nbmf_selftest_mfma_peak.argtypes = [c_int, c_double, dp, dp, dp]
+    lib.nbmf_engine_stats.argtypes = [POINTER(ctypes.c_longlong), POINTER(ctypes.c_longlong), POINTER(ctypes.c_longlong)]
     lib.nbmf_generate.argtypes = [c_void_p, ctypes.c_uint64, c_double, c_double]
     lib.nbmf_generate_slice.argtypes = [c_void_p, ctypes.c_uint64, c_double, c_double, c_int64, c_int64, c_int64]
     lib.nbmf_set_storage.argtypes = [c_void_p, c_int]
@@ -203,8 +208,13 @@ class Context:
         _check(self._lib.nbmf_set_hyper(self._h, float(alpha), float(beta), float(eps), int(projection)))
 
     def upload(self, x, mask=None, transposed=False):
-        """x: the m x n internal matrix, or (transposed=True) the n x m user matrix whose transpose it is."""
-        x = _f64c(x)
+        """x: the m x n internal matrix, or (transposed=True) the n x m user matrix whose transpose it is.
+        A bool / uint8 array goes up as it is, one byte per entry (``nbmf_upload_v``); anything else as float64."""
+        x = np.asarray(x)
+        if x.dtype == np.bool_ or x.dtype == np.uint8:
+            x, x_kind = np.ascontiguousarray(x).view(np.uint8), DATA_U8
+        else:
+            x, x_kind = _f64c(x), DATA_F64
         want = (self.n, self.m) if transposed else (self.m, self.n)
         if x.shape != want:
             raise ValueError(f"data has shape {x.shape}, context expects {want}")
@@ -221,8 +231,8 @@ class Context:
                 kind = MASK_F64
             mptr, ldm = mask.ctypes.data_as(c_void_p), mask.shape[1]
         flags = c_int(0)
-        _check(self._lib.nbmf_upload(self._h, x.ctypes.data_as(c_void_p), x.shape[1], int(bool(transposed)),
-                                     mptr, kind, ldm, byref(flags)))
+        _check(self._lib.nbmf_upload_v(self._h, x.ctypes.data_as(c_void_p), x_kind, x.shape[1], int(bool(transposed)),
+                                       mptr, kind, ldm, byref(flags)))
         self.binary_path = bool(flags.value & FLAG_BINARY_PATH)
         return self.binary_path
 
@@ -431,6 +441,22 @@ def comm_unique_id() -> bytes:
     buf = ctypes.create_string_buffer(128)
     _check(load().nbmf_comm_unique_id(buf))
     return buf.raw
+
+
+def engine_stats():
+    """Process-wide: (fits the single-launch engine served, persistent launches that gave up, nbmf_run calls the
+    launch-per-kernel engine served)."""
+    a, b, c = ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+    _check(load().nbmf_engine_stats(byref(a), byref(b), byref(c)))
+    return a.value, b.value, c.value
+
+
+def mfma_peak(device=0, target_ms=100.0):
+    """The f64 MFMA rate of ``device`` as measured now: ``{"tflops", "cycles_per_mfma_at_2p4GHz", "launch_ms"}``
+    (``nbmf_selftest_mfma_peak``: a loop of bare v_mfma_f64_16x16x4_f64, VGPR accumulators, all SIMDs)."""
+    t, cy, ms = c_double(0), c_double(0), c_double(0)
+    _check(load().nbmf_selftest_mfma_peak(int(device), float(target_ms), byref(t), byref(cy), byref(ms)))
+    return {"tflops": t.value, "cycles_per_mfma_at_2p4GHz": cy.value, "launch_ms": ms.value}
 
 
 def selftest_unary(op, x, device=0):

@@ -41,6 +41,13 @@ def _binary_pattern(A):
     return A.indptr.astype(np.int64), A.indices.astype(np.int32)
 
 
+def _dense(X):
+    """Dense data as the library takes it: bool / uint8 arrays as they are (one byte per entry up to the device,
+    ``nbmf_upload_v``), everything else as float64 (the reference converts every input, _base.py:83)."""
+    X = np.asarray(X)
+    return X if X.dtype in (np.bool_, np.uint8) else np.asarray(X, dtype=np.float64)
+
+
 def upload_any(ctx, X, mask=None, transposed=False):
     """Upload dense or scipy-sparse data: binary sparse patterns (with no mask or a sparse pattern mask) go up as
     CSR (``nbmf_upload_csr``); everything else is densified first, as the reference does (:28-29,106-107)."""
@@ -56,7 +63,7 @@ def upload_any(ctx, X, mask=None, transposed=False):
         X = X.toarray()
     if mask is not None and hasattr(mask, "toarray"):
         mask = mask.toarray()
-    return ctx.upload(np.asarray(X, dtype=np.float64), mask=mask, transposed=transposed)
+    return ctx.upload(_dense(X), mask=mask, transposed=transposed)
 
 
 def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None,
@@ -188,7 +195,7 @@ def w_only_transform(X, H, mask=None, W0=None, n_iter=50, device=0):
     """The loop of ``NBMFMM.transform`` (src/nbmf_mm/_base.py:170-199) on the GPU: ``n_iter``
     simplex-factor updates with ``H`` frozen, then clip to [1e-8, 1] and row-renormalise."""
     if not hasattr(X, "toarray"):
-        X = np.asarray(X, dtype=np.float64)
+        X = _dense(X)
     m, n = X.shape
     k = H.shape[0]
     if W0 is None:
@@ -210,7 +217,7 @@ def device_score(X, H, mask=None, n_iter=50, device=0):
     the mask (:235), then the mean log-likelihood per observed entry of W @ H under ``mask``.
     The reference clips W @ H to [0, 1] first (:210); so does the device sweep (clip_theta)."""
     if not hasattr(X, "toarray"):
-        X = np.asarray(X, dtype=np.float64)
+        X = _dense(X)
     m, n = X.shape
     k = H.shape[0]
     W0 = np.random.uniform(0.1, 0.9, (m, k))          # global RNG, :175

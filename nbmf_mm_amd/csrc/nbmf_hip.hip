@@ -25,6 +25,7 @@
 #include <dlfcn.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -96,6 +97,15 @@
 #endif
 #ifndef NBMF_MASK_PREFETCH
 #define NBMF_MASK_PREFETCH 8   // binary sweeps: row blocks ahead of the tile in hand at which the lane-mask records are pulled into the L2 (0 = off)
+#endif
+#ifndef NBMF_RENORM_TRIP
+#define NBMF_RENORM_TRIP 1   // the likelihood's running product is renormalised once per trip of the sweep's loop instead of per tile (see pass_kernel)
+#endif
+#ifndef NBMF_GEN_PHASED
+#define NBMF_GEN_PHASED 1   // general path: a tile's four table gathers issued together, independent arithmetic while they fly
+#endif
+#ifndef NBMF_GEN_H_WGS
+#define NBMF_GEN_H_WGS 2   // general path, H sweep at K <= 64: workgroups per CU the kernel is compiled for (3 needs <= 168 registers)
 #endif
 #ifndef NBMF_NO_MFMA
 #define NBMF_NO_MFMA 0   // 1 = measurement build: the sweeps without their MFMAs (see NBMF_MFMA in nbmf_pass_kernel.inc)
@@ -785,6 +795,9 @@ void arena_release(ArenaSlot* a) {
       delete a;
     }
 }
+
+// ---- which engine served the fits of this process (nbmf_engine_stats) ----------------------------
+std::atomic<long long> g_engine_persistent_served{0}, g_engine_persistent_aborted{0}, g_engine_launches_served{0};
 
 // ---- the general path's logarithm table: one copy per device and process ------------------------
 const double2* g_logtab[64] = {nullptr};
@@ -2156,6 +2169,7 @@ int run_small_batch(nbmf_ctx* c, int nprob, const double* alpha, const double* b
       if (res[(size_t)p * 4 + 2] != 0 || abort_words[(size_t)p] != 0 || res[(size_t)p * 4] < 1 || res[(size_t)p * 4] > max_iter) {
         c->small.disabled = true;   // a barrier was abandoned: this context keeps to the launches from now on
         ++c->small.aborted;
+        g_engine_persistent_aborted.fetch_add(1, std::memory_order_relaxed);
         if (getenv("NBMF_DEBUG")) fprintf(stderr, "[nbmf] batched persistent fit abandoned (problem %d): one by one\n", p0 + p);
         return NBMF_OK;             // *handled stays false: the caller redoes ALL problems one by one
       }
@@ -2177,6 +2191,7 @@ int run_small_batch(nbmf_ctx* c, int nprob, const double* alpha, const double* b
     HIPCHK(stream_wait_spin(c->stream));
   }
   c->small.runs += nprob;
+  g_engine_persistent_served.fetch_add(nprob, std::memory_order_relaxed);
   *handled = true;
   return NBMF_OK;
 }
@@ -2304,7 +2319,7 @@ int set_device(nbmf_ctx* c) {
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-int nbmf_abi_version(void) { return 2; }   // 2: NBMF_PEER_HANDLE_BYTES 128 -> 192, nbmf_generate_slice, nbmf_set_storage
+int nbmf_abi_version(void) { return 3; }   // 2: NBMF_PEER_HANDLE_BYTES 128 -> 192, nbmf_generate_slice, nbmf_set_storage; 3: nbmf_upload_v (uint8 / bool data), nbmf_selftest_mfma_peak, nbmf_engine_stats
 
 const char* nbmf_last_error(void) { return g_err.c_str(); }
 
@@ -2423,7 +2438,16 @@ int nbmf_set_hyper(nbmf_ctx* c, double alpha, double beta, double eps, int proje
 
 int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const void* mask, int mask_kind,
                 int64_t ldmask, int* out_flags) {
-  if (!c || !x) return fail(NBMF_ERR_ARG, "null context or data");
+  return nbmf_upload_v(c, x, NBMF_DATA_F64, ldx, transposed, mask, mask_kind, ldmask, out_flags);
+}
+
+int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int transposed, const void* mask, int mask_kind,
+                  int64_t ldmask, int* out_flags) {
+  if (!c || !xv) return fail(NBMF_ERR_ARG, "null context or data");
+  if (x_kind != NBMF_DATA_F64 && x_kind != NBMF_DATA_U8) return fail(NBMF_ERR_ARG, "x_kind must be NBMF_DATA_F64 or NBMF_DATA_U8");
+  const size_t xsz = x_kind == NBMF_DATA_U8 ? 1 : 8;   // bytes per element of the host array
+  const double* x = (const double*)xv;
+  const unsigned char* xb = (const unsigned char*)xv;
   if (mask_kind != NBMF_MASK_NONE && !mask) return fail(NBMF_ERR_ARG, "mask_kind set but mask is NULL");
   if (!mask) mask_kind = NBMF_MASK_NONE;
   if (is_sharded(c)) return fail(NBMF_ERR_STATE, "upload before attaching a communicator");
@@ -2440,8 +2464,8 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
     for (int64_t u = 0; u < rows && (guess_bin || guess_mask_bin); ++u) {
       const int64_t uu = (U - 1) * u / (rows > 1 ? rows - 1 : 1);
       for (int64_t v = 0; v < V && v < 4096; ++v) {
-        const double xv = x[uu * ldx + v];
-        if (xv != 0.0 && xv != 1.0) guess_bin = false;
+        const double xe = x_kind == NBMF_DATA_U8 ? (double)xb[uu * ldx + v] : x[uu * ldx + v];
+        if (xe != 0.0 && xe != 1.0) guess_bin = false;
         if (mask_kind == NBMF_MASK_F64) {
           const double mk = ((const double*)mask)[uu * ldmask + v];
           if (mk != 0.0 && mk != 1.0) guess_mask_bin = false;
@@ -2454,11 +2478,11 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   const size_t tiles = (size_t)(c->mA / 16) * (c->nA / 16);
   // staging chunk: <= 256 MiB of raw rows and <= 32768 tile rows (grid.y limit of the pack launch)
   const int64_t chunk_rows_max =
-      std::min<int64_t>(32768 * 16, std::max<int64_t>(PAD, ((int64_t)(256ll << 20) / (V * 8)) / PAD * PAD));
-  double* raw = nullptr;
+      std::min<int64_t>(32768 * 16, std::max<int64_t>(PAD, ((int64_t)(256ll << 20) / (V * (int64_t)xsz)) / PAD * PAD));
+  char* raw = nullptr;
   void* rawm = nullptr;
   struct StagingGuard {   // the raw staging buffers never outlive this call, whichever way it returns
-    double*& a;
+    char*& a;
     void*& b;
     ~StagingGuard() {
       if (a) dfree(a);
@@ -2467,7 +2491,7 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
   } staging_guard{raw, rawm};
   const size_t msz = mask_kind == NBMF_MASK_F64 ? 8 : 1;
   const int64_t chunk_rows = std::min<int64_t>(round_up(U, PAD), chunk_rows_max);
-  HIPCHK(dmalloc(&raw, (size_t)chunk_rows * V * 8));
+  HIPCHK(dmalloc(&raw, (size_t)chunk_rows * V * xsz));
   if (mask) HIPCHK(dmalloc(&rawm, (size_t)chunk_rows * V * msz));
 
   int rc = NBMF_OK;
@@ -2500,7 +2524,7 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
       const int64_t urows_pad = std::min<int64_t>(chunk_rows, round_up(U, PAD) - u0);
       const int64_t urows = std::max<int64_t>(0, std::min<int64_t>(U - u0, urows_pad));
       if (urows > 0) {
-        HIPCHK(hipMemcpy2DAsync(raw, (size_t)V * 8, x + u0 * ldx, (size_t)ldx * 8, (size_t)V * 8, (size_t)urows,
+        HIPCHK(hipMemcpy2DAsync(raw, (size_t)V * xsz, xb + (size_t)u0 * ldx * xsz, (size_t)ldx * xsz, (size_t)V * xsz, (size_t)urows,
                                 hipMemcpyHostToDevice, c->stream));
         if (mask)
           HIPCHK(hipMemcpy2DAsync(rawm, (size_t)V * msz, (const char*)mask + (size_t)u0 * ldmask * msz,
@@ -2509,6 +2533,7 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
       }
       PackArgs a{};
       a.x = raw;
+      a.x_kind = x_kind;
       a.mask = mask ? rawm : nullptr;
       a.mask_kind = mask_kind;
       a.ldx = V;
@@ -2767,6 +2792,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
     if (int rc = run_small(c, max_iter, tol, losses, n_iter, &handled)) return rc;
     if (handled) return NBMF_OK;
   }
+  g_engine_launches_served.fetch_add(1, std::memory_order_relaxed);
 
   // Timeline (N3 of SURVEY Appendix A): the H-pass of iteration t also yields the log-likelihood of
   // the factors after iteration t-1, so loss(t-1) and its stop test are settled before H-update(t).
@@ -3327,6 +3353,56 @@ int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y) {
   HIPCHK(hipMemcpy(y, o, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
   dfree(d);
   dfree(o);
+  return NBMF_OK;
+}
+
+int nbmf_engine_stats(long long* persistent_served, long long* persistent_aborted, long long* launches_served) {
+  if (persistent_served) *persistent_served = g_engine_persistent_served.load(std::memory_order_relaxed);
+  if (persistent_aborted) *persistent_aborted = g_engine_persistent_aborted.load(std::memory_order_relaxed);
+  if (launches_served) *launches_served = g_engine_launches_served.load(std::memory_order_relaxed);
+  return NBMF_OK;
+}
+
+int nbmf_selftest_mfma_peak(int device, double target_ms, double* tflops, double* cycles_per_mfma, double* launch_ms) {
+  if (!(target_ms > 0.0 && target_ms <= 2000.0)) return fail(NBMF_ERR_ARG, "target_ms must be in (0, 2000]");
+  HIPCHK(hipSetDevice(device));
+  DevInfo di;
+  HIPCHK(device_info(device, &di));
+  if (!di.gfx950) return fail(NBMF_ERR_HIP, "device %d is %s, not gfx950", device, di.arch);
+  const int wgs = di.cus * 2;   // 4 waves each: two waves per SIMD (one does as well: the pipe is the limit)
+  double* out = nullptr;
+  HIPCHK(dmalloc(&out, sizeof(double) * (size_t)wgs * 256));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  auto timed = [&](int iters, float* ms) -> hipError_t {
+    hipError_t e;
+    if ((e = hipEventRecord(e0, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(wgs), dim3(256), 0, 0, out, iters, 1.0, 0.5);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipEventRecord(e1, 0)) != hipSuccess) return e;
+    if ((e = hipEventSynchronize(e1)) != hipSuccess) return e;
+    return hipEventElapsedTime(ms, e0, e1);
+  };
+  // a trip is 8 MFMAs of 64 cycles on each of two waves of a SIMD: ~0.43 us at 2.4 GHz.  Warm up and calibrate with a
+  // short launch, then one launch of about target_ms (long enough for the power management to act).
+  float ms = 0;
+  hipError_t e = timed(2000, &ms);
+  if (e == hipSuccess) e = timed(2000, &ms);
+  int iters = 2000;
+  if (e == hipSuccess) {
+    iters = (int)std::min(4.0e6, std::max(2000.0, 2000.0 * target_ms / std::max((double)ms, 1e-3)));
+    e = timed(iters, &ms);
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  dfree(out);
+  if (e != hipSuccess) return fail(NBMF_ERR_HIP, "MFMA peak self-test failed: %s", hipGetErrorString(e));
+  const double mfmas_per_simd = 2.0 * 8.0 * (double)iters;                    // two waves per SIMD
+  const double flop = (double)wgs * 4.0 * 8.0 * (double)iters * 2048.0;       // 16 x 16 x 4 multiply-adds per MFMA and wave
+  if (tflops) *tflops = flop / ((double)ms * 1e-3) * 1e-12;
+  if (cycles_per_mfma) *cycles_per_mfma = (double)ms * 1e-3 * 2.4e9 / mfmas_per_simd;
+  if (launch_ms) *launch_ms = ms;
   return NBMF_OK;
 }
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_hip.SYMBOLS) == declared, "python binding list and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"libnbmf_hip.so does not export {name}"
-    assert lib.nbmf_abi_version() == 2
+    assert lib.nbmf_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
