@@ -27,9 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet fp64 matrix = 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
-PEAK_MEASURED_TFLOPS = 77.8    # a loop of nothing but v_mfma_f64_16x16x4_f64 with VGPR accumulators on all 1024 SIMDs, sustained over 85 ms
-                               # launches: 64.6 cycles per MFMA (tools/microbench3.hip, profiles/r3_f64_mfma_issue_rate_and_clock.txt;
-                               # the bare loop of tools/microbench.hip, AGPR accumulators, measures 72.0)
+# (the MEASURED peak on the line -- roofline.peak_measured -- is taken on the device that ran the bench, after the timed
+#  region: nbmf_selftest_mfma_peak, a ~100 ms loop of nothing but v_mfma_f64_16x16x4_f64 with VGPR accumulators on all SIMDs)
 
 
 def make_shard(M, N, r0, r1, seed, density=0.25, observed=0.9, masked=True):
@@ -236,6 +235,8 @@ def main():
                          "doubles plus float64 weight tiles (a real-valued mask)")
     ap.add_argument("--no-f64-leg", action="store_true",
                     help="skip the extra leg that times the same data on the 8-byte storage path (f64_storage on the line)")
+    ap.add_argument("--no-u8-leg", action="store_true",
+                    help="skip the extra leg that uploads the same V as uint8 (upload.uint8 on the line)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the untimed check of the chosen transport against the host transport (--gpus > 1)")
     args = ap.parse_args()
@@ -312,7 +313,8 @@ def run_rank(args, rank, local_rank, world):
     t_up = time.perf_counter() - t_up
     f64_leg = (world == 1 and args.storage == "auto" and binary_path and not args.device_data and not args.no_f64_leg
                and not args.force_comm)
-    if not f64_leg:
+    u8_leg = world == 1 and binary_path and not args.device_data and not args.force_comm and not args.no_u8_leg
+    if not (f64_leg or u8_leg):
         X = Mk = None
 
     def reset():
@@ -351,9 +353,10 @@ def run_rank(args, rank, local_rank, world):
         return group.max_float(dt), losses
 
     event_stride = 1
+    losses_first = None          # the losses of the first iterations from the initial factors (the uint8 leg compares with them)
     if args.warmup > 0:
         tw0 = time.perf_counter()
-        ctx.run(args.warmup, 0.0)
+        losses_first, _ = ctx.run(args.warmup, 0.0)
         ctx.synchronize()
         warm_ms = 1e3 * (time.perf_counter() - tw0) / args.warmup
         # a timed dispatch costs ~2.5 us: where an iteration is short, the events ride on a sample of the timed region's
@@ -394,7 +397,6 @@ def run_rank(args, rank, local_rank, world):
         ctx.set_hyper(1.2, 1.2, 1e-8, proj)
         ctx.set_storage("f64")
         ctx.upload(X, mask=Mk)
-        X = Mk = None
         reset()
         if args.warmup > 0:
             ctx.run(args.warmup, 0.0)
@@ -410,8 +412,32 @@ def run_rank(args, rank, local_rank, world):
                "frac": (fl / (h64 * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if h64 > 0 else None,
                "wpass_executed_frac": (4.0 / 6.0 * fl / (w64 * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if w64 > 0 else None,
                "executed_frac": (10.0 / 6.0 * fl * (args.steps / dt64) / 1e12) / PEAK_FP64_MFMA_TFLOPS,
+               "hpass_tflops": (fl / (h64 * 1e-3) / 1e12) if h64 > 0 else None,
                "final_nll_per_entry": float(losses64[-1]),
                "rel_nll_vs_u8_path": abs(float(losses64[-1]) - float(losses[-1])) / abs(float(losses[-1]))}
+
+    # the same V handed over as uint8 (one byte per entry, nbmf_upload_v) instead of float64: upload time and rate, and
+    # the first iterations of the fit against those of the float64 upload (the same bits)
+    up8 = None
+    if u8_leg:
+        X8 = X.astype(np.uint8)
+        X = None
+        ctx = _hip.Context(r1 - r0, N, K, device=dev_index)
+        ctx.set_hyper(1.2, 1.2, 1e-8, proj)
+        t8 = time.perf_counter()
+        ctx.upload(X8, mask=Mk)
+        t8 = time.perf_counter() - t8
+        reset()
+        l8, _ = ctx.run(min(3, args.steps + args.warmup), 0.0)
+        ctx.close()
+        first = (losses_first if losses_first is not None else losses)[:len(l8)]
+        nb = X8.nbytes + (Mk.nbytes if masked else 0)
+        up8 = {"bytes": nb, "seconds": t8, "GBps_pcie_inclusive": nb / t8 / 1e9,
+               "host_array": "uint8 V + bool mask, 1 byte per entry each (nbmf_upload_v)",
+               "fit_equals_f64_upload_bitwise": bool(len(first) == len(l8) and all(float(a) == float(b) for a, b in zip(first, l8)))}
+        X8 = None
+    X = Mk = None
+    peak_meas = _hip.mfma_peak(dev_index, 100.0) if rank == 0 else None
 
     if rank == 0:
         its = args.steps / dt
@@ -422,6 +448,8 @@ def run_rank(args, rank, local_rank, world):
         flop_pass = 6.0 * m_loc * N * K
         achieved = flop_pass / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
         traffic, traffic_src = profiled_traffic(M, N, K, masked, world)
+        if f64 and f64.get("hpass_tflops"):
+            f64["frac_of_measured"] = f64["hpass_tflops"] / peak_meas["tflops"]
         by_proj = {args.projection: its, other: args.steps / dt_other}
         out = {
             "metric": "MM-iterations/sec", "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps,
@@ -448,7 +476,10 @@ def run_rank(args, rank, local_rank, world):
             "roofline": {"bound": "mfma", "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-                         "peak_measured": PEAK_MEASURED_TFLOPS, "frac_of_measured": achieved / PEAK_MEASURED_TFLOPS,
+                         "peak_measured": peak_meas["tflops"], "frac_of_measured": achieved / peak_meas["tflops"],
+                         "peak_measured_how": "nbmf_selftest_mfma_peak on this device after the timed region: %.1f ms of bare "
+                                              "v_mfma_f64_16x16x4_f64 (VGPR accumulators, two waves per SIMD): %.2f cycles per MFMA "
+                                              "at the nominal 2.4 GHz" % (peak_meas["launch_ms"], peak_meas["cycles_per_mfma_at_2p4GHz"]),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "bytes per launch (PMC: (2*FETCH_SIZE + WRITE_SIZE) KiB; compulsory: the data image the sweep "
                                          "reads -- lane-mask records, m*N/4 bytes, on the binary path -- + 2*chunks*K*N*8 slab bytes + one "
@@ -463,7 +494,8 @@ def run_rank(args, rank, local_rank, world):
                          "executed_frac": (10.0 * m_loc * N * K * its / 1e12) / PEAK_FP64_MFMA_TFLOPS,
                          "wpass_executed_frac": (4.0 * m_loc * N * K / (w_ms * 1e-3) / 1e12) / PEAK_FP64_MFMA_TFLOPS if w_ms > 0 else None,
                          "iteration_frac": (12.0 * m_loc * N * K * its / 1e12) / PEAK_FP64_MFMA_TFLOPS},
-            "upload": {"seconds": t_up, "GBps_pcie_inclusive": (bytes_up / t_up / 1e9) if bytes_up else None},
+            "upload": {"bytes": bytes_up, "seconds": t_up, "GBps_pcie_inclusive": (bytes_up / t_up / 1e9) if bytes_up else None,
+                       "host_array": "float64 V + bool mask" if bytes_up else None, "uint8": up8},
         }
         if world == 1 and not args.no_cpu_baseline:
             # the whole matrix needs >= 48 GiB of NumPy temporaries per iteration and ~90 s each; the

@@ -135,6 +135,11 @@ namespace {
 // error plumbing
 // ------------------------------------------------------------------------------------------
 thread_local std::string g_err;
+// which engine served the fits of this process (nbmf_engine_stats): fits the single-launch engine ran to the end,
+// persistent launches that gave up, qualifying fits it declined because the context's kernel had given up before, and
+// nbmf_run calls served by the launches
+std::atomic<long long> g_engine_persistent_served{0}, g_engine_persistent_aborted{0}, g_engine_persistent_declined{0},
+    g_engine_launches_served{0};
 
 int fail(int code, const char* fmt, ...) {
   char buf[1024];
@@ -795,9 +800,6 @@ void arena_release(ArenaSlot* a) {
       delete a;
     }
 }
-
-// ---- which engine served the fits of this process (nbmf_engine_stats) ----------------------------
-std::atomic<long long> g_engine_persistent_served{0}, g_engine_persistent_aborted{0}, g_engine_launches_served{0};
 
 // ---- the general path's logarithm table: one copy per device and process ------------------------
 const double2* g_logtab[64] = {nullptr};
@@ -1743,7 +1745,7 @@ int small_parts(const nbmf_ctx* c, long long sweep_blocks, long long strips) {
 bool small_eligible(const nbmf_ctx* c, int cus) {
   // (a progress callback does not change the engine: the run takes milliseconds, its losses are reported right after
   //  it, in the same batches -- so a verbose fit and a silent one give the same bits)
-  if (c->small.disabled || is_sharded(c) || c->KS != 1 || c->KB > 2 || c->timing) return false;
+  if (is_sharded(c) || c->KS != 1 || c->KB > 2 || c->timing) return false;
   cus = std::min(cus, SMALL_MAX_WGS);   // a device reporting more CUs than the buffers were sized for uses that many of them
   if (const char* e = getenv("NBMF_PERSISTENT"))
     if (atoi(e) == 0) return false;
@@ -1752,7 +1754,14 @@ bool small_eligible(const nbmf_ctx* c, int cus) {
   if (const char* e = getenv("NBMF_SMALL_TILES")) max_tiles = atoll(e);
   const int NW = sm_waves(c->KB), PH = small_parts(c, Rbe, Cbe), PW = small_parts(c, Cbe, Rbe);
   const bool fits = (Rbe + (long long)PH * NW - 1) / ((long long)PH * NW) <= SM_TPW && (Cbe + (long long)PW * NW - 1) / ((long long)PW * NW) <= SM_TPW;
-  return fits && Cbe <= 128 && Cbe * PH <= cus && Rbe * PW <= cus && Rbe * Cbe <= max_tiles;
+  if (!(fits && Cbe <= 128 && Cbe * PH <= cus && Rbe * PW <= cus && Rbe * Cbe <= max_tiles)) return false;
+  // the problem qualifies.  A context whose persistent kernel once gave up keeps to the launches -- counted, so that a
+  // test which names the single-launch engine can tell that it did not run (nbmf_engine_stats)
+  if (c->small.disabled) {
+    g_engine_persistent_declined.fetch_add(1, std::memory_order_relaxed);
+    return false;
+  }
+  return true;
 }
 
 // Admission of persistent kernels, per device and process-wide: a persistent kernel needs ALL its workgroups
@@ -1989,6 +1998,7 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
     // a barrier was abandoned (workgroups not co-resident for too long): back to the state at entry, and this
     // context keeps to the five-kernel path from now on
     ++w.aborted;
+    g_engine_persistent_aborted.fetch_add(1, std::memory_order_relaxed);
     w.disabled = true;
     HIPCHK(hipMemcpyAsync(c->Wn, w.snapW, fw, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->Hn, w.snapH, fh, hipMemcpyDeviceToDevice, c->stream));
@@ -2015,6 +2025,7 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   HIPCHK(stream_wait_spin(c->stream));
   *n_iter = res[0];
   *handled = true;
+  g_engine_persistent_served.fetch_add(1, std::memory_order_relaxed);
   if (c->progress && c->progress_every > 0)   // the reports a launch-by-launch run would have made, in the same batches
     for (int first = 0; first < res[0]; first += c->progress_every)
       c->progress(c->progress_user, first, std::min(c->progress_every, res[0] - first), losses + first);
@@ -3358,7 +3369,9 @@ int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y) {
 
 int nbmf_engine_stats(long long* persistent_served, long long* persistent_aborted, long long* launches_served) {
   if (persistent_served) *persistent_served = g_engine_persistent_served.load(std::memory_order_relaxed);
-  if (persistent_aborted) *persistent_aborted = g_engine_persistent_aborted.load(std::memory_order_relaxed);
+  // (a fit declined because the context's kernel gave up earlier counts as given up: it ran on the other engine)
+  if (persistent_aborted)
+    *persistent_aborted = g_engine_persistent_aborted.load(std::memory_order_relaxed) + g_engine_persistent_declined.load(std::memory_order_relaxed);
   if (launches_served) *launches_served = g_engine_launches_served.load(std::memory_order_relaxed);
   return NBMF_OK;
 }

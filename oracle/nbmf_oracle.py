@@ -166,15 +166,19 @@ def solve(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=N
     return W_out, H_out, losses, 0.0, it + 1
 
 
-def w_only_transform(X, H, mask=None, W0=None, n_iter=50):
+def w_only_transform(X, H, mask=None, W0=None, n_iter=50, track_positive=False):
     """Simplex-factor-only loop with the Beta factor frozen (src/nbmf_mm/_base.py:170-199).
 
     ``W0`` (m,k) defaults to a draw from the GLOBAL legacy RNG, as the reference does (:175).
     Always the simplex-W form, whatever the fitted orientation; eps is hard-coded 1e-8.
+    ``track_positive``: also return which rows kept every entry positive through all iterations -- the start is NOT
+    on the simplex (:175), so W @ H can exceed 1, ratios turn negative, and a row that goes through that is on a
+    chaotic trajectory in the reference itself (tests/test_oracle_golden.py::test_transform_start_is_chaotic_on_a_few_rows).
     """
     m = X.shape[0]
     k = H.shape[0]
     W = np.random.uniform(0.1, 0.9, (m, k)) if W0 is None else W0
+    positive = np.ones(m, dtype=bool)
     for _ in range(n_iter):
         Wt = W.T
         theta_t = H.T @ Wt
@@ -188,9 +192,18 @@ def w_only_transform(X, H, mask=None, W0=None, n_iter=50):
         Wt = Wt / X.shape[1]
         Wt = Wt / Wt.sum(axis=0, keepdims=True)
         W = Wt.T
+        positive &= (W > 0).all(axis=1)
     W = np.clip(W, 1e-8, 1.0)                   # :196
     W = W / W.sum(axis=1, keepdims=True)        # :198
-    return W
+    return (W, positive) if track_positive else W
+
+
+def score_rows(X, W, H, mask=None):
+    """Per-row sums of the log-likelihood terms of :func:`score` (their total / n_obs is the score)."""
+    recon = np.clip(W @ H, 0.0, 1.0)
+    eps = 1e-8
+    xm = X if mask is None else X * mask
+    return np.sum(xm * np.log(recon + eps) + (1 - xm) * np.log(1 - recon + eps), axis=1)
 
 
 def score(X, W, H, mask=None):

@@ -9,6 +9,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
+def hip():
+    from nbmf_mm_amd import _hip
+    assert _hip.device_count() >= 1, "no MI355X visible: the GPU tests must run on the GPU box"
+    return _hip
+
+
+@pytest.fixture(scope="module")
 def data():
     from nbmf_mm_amd._utils import generate_synthetic_binary_data
     X, _, _ = generate_synthetic_binary_data(60, 45, 5, random_state=42)
@@ -618,3 +625,54 @@ def test_generate_slice_is_the_slice_of_the_global_matrix():
     with pytest.raises(ValueError):
         with _hip.Context(10, 10, 2) as ctx:
             ctx.generate(1, row0=0, col0=5, n_global=12)          # the slice does not fit the global width
+
+
+@pytest.mark.parametrize("orientation", ["beta-dir", "dir-beta"])
+@pytest.mark.parametrize("dtype", [np.bool_, np.uint8])
+def test_bool_and_uint8_data_go_up_as_bytes_and_fit_the_same_bits(hip, dtype, orientation):
+    """Dense bool / uint8 V is handed to the library as it is (nbmf_upload_v, one byte per entry) instead of through the
+    float64 copy of _base.py:83: the fit, transform and score are those of the float64 array, bit for bit."""
+    from nbmf_mm_amd import NBMF
+    r = np.random.default_rng(21)
+    Xf = (r.random((150, 210)) < 0.3).astype(np.float64)
+    Xb = Xf.astype(dtype)
+    mask = r.random((150, 210)) < 0.85
+    kw = dict(n_components=7, max_iter=25, tol=0, random_state=3, orientation=orientation)
+    for mk in (None, mask):
+        a = NBMF(**kw).fit(Xf, mask=mk)
+        b = NBMF(**kw).fit(Xb, mask=mk)
+        np.testing.assert_array_equal(a.loss_curve_, b.loss_curve_)
+        np.testing.assert_array_equal(a.W_, b.W_)
+        np.testing.assert_array_equal(a.components_, b.components_)
+    np.random.seed(4)
+    Ta = a.transform(Xf[:40])
+    np.random.seed(4)
+    Tb = a.transform(Xb[:40])
+    np.testing.assert_array_equal(Ta, Tb)
+    np.random.seed(4)
+    sa = a.score(Xf, mask=mask)
+    np.random.seed(4)
+    assert a.score(Xb, mask=mask) == sa
+    # the library sees bytes: the byte-code storage path, whatever nbmf_set_storage would pick for doubles
+    with hip.Context(150, 210, 7) as ctx:
+        assert ctx.upload(Xb, mask=mask) is True
+        ctx.set_storage("f64")                       # forced 8-byte storage from 1-byte host data works too
+        assert ctx.upload(Xb, mask=mask) is False
+    if dtype is np.uint8:
+        bad = Xb.copy()
+        bad[3, 5] = 7
+        with pytest.raises(ValueError, match="must be binary"):
+            NBMF(**kw).fit(bad)
+
+
+def test_measured_mfma_peak_is_near_the_datasheet(hip):
+    """nbmf_selftest_mfma_peak (bench.py's roofline.peak_measured): a loop of bare f64 MFMAs on this device.  The
+    datasheet says 64 cycles per MFMA and SIMD (78.6 TFLOP/s at 2.4 GHz); round 3 measured 64.5-64.7 with VGPR
+    accumulators.  A reading far off either way means the kernel no longer measures what it says (e.g. hipcc has moved
+    the accumulators to AGPRs: ~70 cycles)."""
+    p = hip.mfma_peak(0, 50.0)
+    assert 30.0 <= p["launch_ms"] <= 120.0
+    assert 63.0 <= p["cycles_per_mfma_at_2p4GHz"] <= 68.0, p
+    assert 74.0 <= p["tflops"] <= 80.0, p
+    a, b, c = hip.engine_stats()
+    assert a >= 0 and b >= 0 and c >= 0

@@ -247,6 +247,40 @@ def test_config5_sparse_as_dense_with_restarts():
     np.testing.assert_allclose(Wi[samp].T, _h_slice(Ycols, None, Wint, H_init[:, samp]), rtol=0, atol=1e-12)
 
 
+def test_config5_shape_as_dense_uint8_equals_the_csr_upload():
+    """configs[4] "sparse-as-dense": the SAME 360000 x 17000 matrix handed over as a dense uint8 array (6.1 GB of host
+    memory, nbmf_upload_v; as float64 it would be 49 GB) and as scipy CSR (nbmf_upload_csr): both are byte codes on the
+    device, so the two fits are the same bits -- K=128, dir-beta, through the estimator, which passes uint8 on without
+    the float64 copy of _base.py:83."""
+    import scipy.sparse as sp
+    from nbmf_mm_amd import NBMF, _hip
+    Mv, Nv, K = 360000, 17000, 128
+    X8 = np.zeros((Mv, Nv), dtype=np.uint8)
+    r = np.random.default_rng(9)
+    for b0 in range(0, Mv, 8192):
+        rows = min(8192, Mv - b0)
+        flat = np.unique(r.integers(0, rows * Nv, r.binomial(rows * Nv, 0.02)))
+        X8[b0:b0 + rows].reshape(-1)[flat] = 1
+    assert X8.nbytes == Mv * Nv and 0.015 < X8.mean(dtype=np.float64) < 0.025
+    V = sp.csr_matrix(X8)
+    kw = dict(n_components=K, max_iter=3, tol=0, orientation="dir-beta", random_state=11)
+    served0 = _hip.engine_stats()
+    dense = NBMF(**kw).fit(X8)
+    sparse = NBMF(**kw).fit(V)
+    assert _hip.engine_stats()[2] - served0[2] == 2
+    np.testing.assert_array_equal(dense.loss_curve_, sparse.loss_curve_)
+    np.testing.assert_array_equal(dense.W_, sparse.W_)
+    np.testing.assert_array_equal(dense.components_, sparse.components_)
+    assert _monotone(dense.loss_curve_) and dense.W_.shape == (Mv, K)
+    # ... and the context says which path it took: byte codes, straight from the bytes
+    with _hip.Context(Nv, Mv, K) as ctx:
+        assert ctx.upload(X8, transposed=True) is True and ctx.n_obs() == float(Mv) * Nv
+    # a uint8 value that is not 0 or 1 is the reference's "X must be binary" (_base.py:90-91), found by the device pack
+    X8[Mv // 2, Nv // 3] = 2
+    with pytest.raises(ValueError, match="must be binary"):
+        NBMF(**kw).fit(X8)
+
+
 # ------------------------------------------------------------------------------------------------------
 # configs[3] WHOLE: V 262144 x 8192, K=64 -- on one context, and as 8 ranks (32768 rows each) that share the one
 # GPU of the box: 4 processes x 2 ranks (the box admits at most 6 GPU processes at once; ranks of one process are

@@ -4,7 +4,7 @@ LIBS="$1"; shift
 for cfg in "$@"; do
   for rep in 1 2; do
     for lib in $LIBS; do
-      NBMF_HIP_LIBRARY=$PWD/$lib python bench.py --no-cpu-baseline $cfg 2>/dev/null | tail -1 > gpurun_out/ab.json
+      NBMF_HIP_LIBRARY=$PWD/$lib python bench.py --no-cpu-baseline --no-u8-leg $cfg 2>/dev/null | tail -1 > gpurun_out/ab.json
       echo -n "[$cfg] $(basename $lib) "; python tools/benchline.py gpurun_out/ab.json | cut -c50-
     done
   done

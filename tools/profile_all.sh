@@ -12,7 +12,7 @@
 #   shard8192   the strong-scaling shard of configs[2]: 8192 x 8192, K=64, no communicator
 export TMPDIR=/tmp
 O=gpurun_out/$1; shift; mkdir -p $O
-B="python3 bench.py --no-cpu-baseline --no-f64-leg"
+B="python3 bench.py --no-cpu-baseline --no-f64-leg --no-u8-leg"
 SQ1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY"
 SQ2="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_COEXEC_CYCLES"
 SQ3="SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_INSTS_SMEM"

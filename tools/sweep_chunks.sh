@@ -3,6 +3,6 @@
 # for one bench configuration.  usage: tools/sweep_chunks.sh "<bench args>" "<min_blocks list>" "<target list>"
 CFG=$1
 for mb in $2; do for tg in $3; do
-  NBMF_MIN_BLOCKS=$mb NBMF_TARGET_WGS=$tg python bench.py --no-cpu-baseline --no-f64-leg $CFG 2>/dev/null | tail -1 > gpurun_out/ab.json
+  NBMF_MIN_BLOCKS=$mb NBMF_TARGET_WGS=$tg python bench.py --no-cpu-baseline --no-f64-leg --no-u8-leg $CFG 2>/dev/null | tail -1 > gpurun_out/ab.json
   echo -n "[$CFG] min_blocks $mb target $tg: "; python tools/benchline.py gpurun_out/ab.json | cut -c50-
 done; done
