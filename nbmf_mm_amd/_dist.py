@@ -158,17 +158,26 @@ def attach_fastest(ctx, group, reset, shard_axis=0, candidates=("peer", "rccl"),
             continue                                  # refused on some rank: every rank got the same answer
         finally:
             ctx.set_peer_timeout_ms(0.0)
+        # Every rank walks through the SAME collectives whatever happened to it locally -- agree, (barrier,) max, agree --
+        # or a rank whose warm-up failed would answer a healthy rank's barrier with its float, and the job would die
+        # instead of moving on to the next transport.
+        t, ok = float("inf"), True
         try:
             reset()
             ctx.run(2, 0.0)
             ctx.synchronize()
-            group.barrier()
-            t0 = time.perf_counter()
-            ctx.run(int(iters), 0.0)
-            ctx.synchronize()
-            t, ok = time.perf_counter() - t0, True
         except _REFUSED:
-            t, ok = float("inf"), False
+            ok = False
+        ok = group.agree(ok)                          # a warm-up that failed anywhere: nobody times this transport
+        if ok:
+            group.barrier()
+            try:
+                t0 = time.perf_counter()
+                ctx.run(int(iters), 0.0)
+                ctx.synchronize()
+                t = time.perf_counter() - t0
+            except _REFUSED:
+                ok = False
         t = group.max_float(t)
         ok = group.agree(ok)
         ctx.comm_detach()

@@ -251,6 +251,10 @@ def _worker_fastest(rank, world, port, q, kind):
 
         def run(self, n, tol):
             self.calls.append(f"run{n}")
+            # fault injection AFTER a clean attach, on one rank only: the peer transport's exchange times out in the
+            # warm-up ("run_warmup") or in the timed run ("run_timed") -- NBMFHipError out of ctx.run
+            if self.attached == "peer" and (("run_warmup" in self.fail and n == 2) or ("run_timed" in self.fail and n != 2)):
+                raise _hip.NBMFHipError("peer exchange timed out")
             if self.attached == "peer" and rank == 1:
                 time.sleep(0.05 * n)
 
@@ -267,6 +271,13 @@ def _worker_fastest(rank, world, port, q, kind):
         out["peer_only"] = _dist.attach_fastest(c, dist, lambda: None, iters=2)[0], c.attached
         c = Ctx(["export", "rccl"])                        # nothing attaches: host transport
         out["none"] = _dist.attach_fastest(c, dist, lambda: None, iters=2)[0], c.calls[-1]
+        # a transport that attaches everywhere but cannot exchange on ONE rank -- in the warm-up, or only in the timed
+        # run: the healthy rank and the failed one keep walking through the same collectives, the transport (and its
+        # two-panel form) is dropped by both, and the next one is timed and kept
+        for where, who in (("run_warmup", 1), ("run_timed", 0)):
+            c = Ctx([where] if rank == who else [])
+            best, timings = _dist.attach_fastest(c, dist, lambda: None, candidates=("peer", "peer2", "rccl"), iters=3)
+            out[where] = best, sorted(timings), c.attached, c.calls.count("peer")
         q.put((rank, out))
     finally:
         dist.close()
@@ -292,6 +303,8 @@ def test_attach_fastest_picks_by_the_slowest_rank(kind):
         assert n_reset == 4                                  # before each trial and after the final attach
         assert r["peer_only"] == ("peer", "peer")
         assert r["none"] == ("host", "host")
+        for where in ("run_warmup", "run_timed"):
+            assert r[where] == ("rccl", ["rccl"], "rccl", 1)     # peer attached once, was dropped, peer2 never tried
     assert res[0]["slow_peer"][1] == res[1]["slow_peer"][1]  # the max over ranks is what every rank sees
 
 
