@@ -25,7 +25,9 @@ class NBMFMM(BaseEstimator, TransformerMixin):
 
     Parameters follow src/nbmf_mm/_base.py:63-66.  Extensions: ``projection`` (alias
     ``projection_method``) in {"normalize", "duchi"} (README.md:27-35 of the reference), ``n_init``
-    (README.md:144: keep the best of several random restarts) and ``device``.
+    (README.md:144: keep the best of several random restarts), ``device``, and ``n_gpus`` / ``devices``: ``fit`` with the
+    rows of X sharded over several GPUs of this machine, driven from this one process (SURVEY section 5's config row;
+    one exchange of the K x N H-step products per iteration, BASELINE.json's north star) -- same results to 1e-12.
 
     Attributes after ``fit``: ``W_`` (n_samples, k), ``components_`` (k, n_features),
     ``loss_curve_`` / ``objective_history_``, ``loss_`` / ``reconstruction_err_``, ``n_iter_``
@@ -34,7 +36,7 @@ class NBMFMM(BaseEstimator, TransformerMixin):
 
     def __init__(self, n_components=10, alpha=1.2, beta=1.2, max_iter=2000, tol=1e-5, W_init=None,
                  H_init=None, init=None, random_state=None, verbose=0, orientation="beta-dir",
-                 projection="normalize", projection_method=None, n_init=1, device=0):
+                 projection="normalize", projection_method=None, n_init=1, device=0, n_gpus=1, devices=None):
         self.n_components = n_components
         self.alpha = alpha
         self.beta = beta
@@ -50,6 +52,8 @@ class NBMFMM(BaseEstimator, TransformerMixin):
         self.projection_method = projection_method
         self.n_init = n_init
         self.device = device
+        self.n_gpus = n_gpus            # fit() shards the rows of X over this many GPUs from this one process
+        self.devices = devices          # ... these ones (default 0 .. n_gpus-1); transform / score use `device`
 
     # -- helpers -----------------------------------------------------------------------------
     def _normalize_orientation(self, orientation):
@@ -105,7 +109,8 @@ class NBMFMM(BaseEstimator, TransformerMixin):
         n_init = int(self.n_init)
         if n_init < 1:
             raise ValueError("n_init must be >= 1")
-        if n_init > 1 and not self.verbose:
+        multi = dict(n_gpus=self.n_gpus, devices=self.devices) if (int(self.n_gpus) != 1 or self.devices is not None) else {}
+        if n_init > 1 and not self.verbose and not multi:
             # restarts share one upload and one library call; small problems run several at a time in one launch
             best, _ = nbmf_mm_restarts(
                 X, self.n_components, n_init, max_iter=self.max_iter, tol=self.tol, alpha=self.alpha, beta=self.beta,
@@ -122,7 +127,7 @@ class NBMFMM(BaseEstimator, TransformerMixin):
                 Y=X, n_components=self.n_components, max_iter=self.max_iter, tol=self.tol,
                 alpha=self.alpha, beta=self.beta, W_init=self.W_init, H_init=self.H_init, mask=mask,
                 random_state=seed, verbose=self.verbose, orientation=orientation,
-                projection=self._projection(), device=self.device)
+                projection=self._projection(), device=self.device, **multi)
             if best is None or result[2][-1] < best[2][-1]:
                 best = result
         W, H, losses, _, n_iter = best

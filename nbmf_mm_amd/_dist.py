@@ -228,9 +228,9 @@ def fit_sharded(V_local, global_shape, offset, n_components, group, orientation=
     returns ``(W, H, losses, n_iter)`` with W (rows_here, k) and H (k, cols_here).
     Custom inits are GLOBAL arrays; under dir-beta they are swapped only if BOTH are given (:122-123).
     """
-    from ._solver import _projection_code, upload_any
+    from ._solver import _dense, _projection_code, upload_any
     if not hasattr(V_local, "toarray"):
-        V_local = np.asarray(V_local, dtype=np.float64)
+        V_local = _dense(V_local)
     M, N = global_shape
     K = int(n_components)
     if orientation not in ("beta-dir", "dir-beta"):
@@ -260,6 +260,105 @@ def fit_sharded(V_local, global_shape, offset, n_components, group, orientation=
         Wk, Hk = ctx.get_factors()
     W_out, H_out = (Hk.T, Wk) if transposed else (Wk.T, Hk)           # un-transpose, _solver.py:178-184
     return W_out, H_out, [float(v) for v in losses], n_iter
+
+
+def fit_in_process(V, n_components, n_gpus, devices=None, orientation="beta-dir", max_iter=500, tol=1e-5, alpha=1.2,
+                   beta=1.2, W_init=None, H_init=None, mask=None, random_state=None, verbose=0, eps=1e-8,
+                   projection="normalize", transport="auto", _rank_fit=None):
+    """``nbmf_mm_solver(..., n_gpus=N)``: the fit of the WHOLE matrix V sharded by rows over ``n_gpus`` GPUs from ONE
+    process -- one host thread, context and stream per GPU (the library calls release the GIL), rank r on
+    ``devices[r]`` (default: devices 0 .. N-1) with rows ``shard_bounds(M, N, r)`` of V and of the mask (views, no
+    copies).  The ranks' exchange arenas are addressed directly (same process: no IPC handles; peer access between the
+    devices), RCCL or the host transport otherwise (``transport="auto"``: the first that attaches on every rank).
+
+    Same signature logic and return value as the single-GPU solver (src/nbmf_mm/_solver.py:61-216): the global RNG is
+    seeded and drawn from ONCE, in the reference's order (:102-129), the loop runs to ``max_iter`` or the stop rule
+    (all ranks decide on the same summed loss), and ``(W (M,k), H (k,N), losses, 0.0, n_iter)`` comes back with the
+    split factor's slices put together.  Differs from ``n_gpus=1`` by the order of the sums over ranks only (<= 1e-12).
+    Several ranks may name the same device (a rehearsal on one GPU): their kernels wait for each other, so the process
+    must have been started with GPU_MAX_HW_QUEUES >= 2 * n_gpus (checked)."""
+    import os
+    import threading
+    from . import _rendezvous
+    from ._solver import _draw_init, _projection_code, _touch_up
+    _projection_code(projection)
+    n_gpus = int(n_gpus)
+    if n_gpus < 1:
+        raise ValueError("n_gpus must be >= 1")
+    if int(max_iter) < 1:
+        raise ValueError("max_iter must be >= 1")
+    devices = list(range(n_gpus)) if devices is None else [int(d) for d in devices]
+    if len(devices) != n_gpus:
+        raise ValueError(f"devices names {len(devices)} GPUs, n_gpus is {n_gpus}")
+    if _rank_fit is None:
+        n_dev = _hip.device_count()
+        if any(d < 0 or d >= n_dev for d in devices):
+            raise ValueError(f"devices {devices} but {n_dev} GPUs are visible")
+        if len(set(devices)) < n_gpus and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 2 * n_gpus:
+            raise ValueError(f"{n_gpus} ranks on {len(set(devices))} device(s): ranks that share a GPU wait for each other inside "
+                             f"kernels, so their streams need hardware queues of their own -- start the process with "
+                             f"GPU_MAX_HW_QUEUES={2 * n_gpus} or more")
+    if not hasattr(V, "toarray"):
+        from ._solver import _dense
+        V = _dense(V)
+    elif not hasattr(V, "indptr") or V.format != "csr":
+        V = V.tocsr()
+    if mask is not None and hasattr(mask, "toarray"):
+        mask = mask.tocsr()
+    M, N = V.shape
+    K = int(n_components)
+    transposed = orientation == "dir-beta"
+    if orientation not in ("beta-dir", "dir-beta"):
+        raise ValueError(f"Unknown orientation: {orientation}")
+    # the reference's seeding and draws, once (:102-129; internal shapes, :113-123), handed to the ranks as GLOBAL inits
+    if random_state is not None:
+        np.random.seed(random_state)
+    m_int, n_int = (N, M) if transposed else (M, N)
+    if transposed and W_init is not None and H_init is not None:
+        W_init, H_init = np.asarray(H_init).T, np.asarray(W_init).T
+    Wi, Hi = _draw_init(m_int, K, n_int, W_init, H_init)                 # (m_int, k), (k, n_int)
+    Wi, Hi = np.asarray(Wi, dtype=np.float64), np.asarray(Hi, dtype=np.float64)
+    if Wi.shape != (m_int, K) or Hi.shape != (K, n_int):
+        raise ValueError(f"operands could not be broadcast together: W_init/H_init give {Wi.T.shape}, {Hi.shape}; "
+                         f"expected ({K},{m_int}), ({K},{n_int})")
+    W_user, H_user = (Hi.T, Wi.T) if transposed else (Wi, Hi)            # what fit_sharded swaps back (:122-123)
+    rank_fit = fit_sharded if _rank_fit is None else _rank_fit
+    groups = _rendezvous.LocalGroup.make(n_gpus)
+    results, errors = [None] * n_gpus, [None] * n_gpus
+
+    def body(r):
+        r0, r1 = shard_bounds(M, n_gpus, r)
+        try:
+            with groups[r] as g:
+                results[r] = rank_fit(V[r0:r1], (M, N), r0, K, g, orientation=orientation, shard="rows", max_iter=max_iter,
+                                      tol=tol, alpha=alpha, beta=beta, W_init=W_user, H_init=H_user,
+                                      mask_local=None if mask is None else mask[r0:r1], random_state=None, eps=eps,
+                                      projection=projection, device=devices[r], transport=transport)
+        except BaseException as e:                                       # noqa: B902 (re-raised in the caller's thread)
+            errors[r] = e
+
+    threads = [threading.Thread(target=body, args=(r,), name=f"nbmf-rank-{r}") for r in range(n_gpus)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    first = [e for e in errors if e is not None and not isinstance(e, ConnectionError)] or [e for e in errors if e is not None]
+    if first:
+        raise first[0]
+    losses, n_iter = results[0][2], results[0][3]
+    # V is split by rows in either orientation: every rank comes back with ITS rows of W (the simplex factor under
+    # beta-dir, the Beta factor under dir-beta) and with the whole of H, the same bits on every rank
+    W = np.concatenate([res[0] for res in results], axis=0)
+    H = results[0][1]
+    W, H = _touch_up(W, H, orientation)
+    losses = [float(v) for v in losses]
+    if verbose > 0:
+        for it, loss in enumerate(losses):
+            if it % 10 == 0:
+                print(f"Iter {it:4d}: Loss = {loss:.6f}", flush=True)   # :165-166 (after the run: the ranks run unobserved)
+        if n_iter < int(max_iter):
+            print(f"Converged at iteration {n_iter - 1}")                # :172-173
+    return W, H, losses, 0.0, n_iter
 
 
 def fit_restarts(V, n_components, group, n_init, random_state=0, device=0, **solver_kwargs):

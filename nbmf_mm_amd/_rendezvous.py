@@ -258,6 +258,76 @@ class SingleGroup:
         self.close()
 
 
+class LocalGroup:
+    """``world`` ranks that are THREADS of one process (``NBMF(n_gpus=N)``: one host thread, context and stream per GPU):
+    the same small interface as :class:`Group`, over a barrier and a shared table instead of sockets.  ``make(world)``
+    returns the ranks' group objects.  A rank that fails calls ``abort()`` (its ``__exit__`` does, on an exception): the
+    others' collectives then raise ``ConnectionError`` instead of waiting for it."""
+
+    class _Shared:
+        def __init__(self, world, timeout):
+            import threading
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+            self.timeout = timeout
+
+    def __init__(self, shared, rank, world):
+        self._s, self.rank, self.world = shared, rank, world
+
+    @classmethod
+    def make(cls, world, timeout=None):
+        shared = cls._Shared(int(world), timeout)
+        return [cls(shared, r, int(world)) for r in range(int(world))]
+
+    def _wait(self):
+        import threading
+        try:
+            self._s.barrier.wait(self._s.timeout)
+        except threading.BrokenBarrierError:
+            raise ConnectionError("another rank of this process has failed") from None
+
+    def all_gather(self, obj):
+        self._s.slots[self.rank] = obj
+        self._wait()                       # everybody has written
+        out = list(self._s.slots)
+        self._wait()                       # everybody has read: the table may be written again
+        return out
+
+    def broadcast(self, obj, src=0):
+        return self.all_gather(obj if self.rank == src else None)[src]
+
+    def barrier(self):
+        self._wait()
+
+    def all_reduce(self, arr, op="sum"):
+        parts = self.all_gather(np.array(arr, copy=True))
+        acc = np.array(parts[0], copy=True)
+        f = {"sum": np.add, "min": np.minimum, "max": np.maximum}[op]
+        for p in parts[1:]:                # rank order on every rank: identical bits
+            f(acc, p, out=acc)
+        arr[...] = acc
+        return arr
+
+    def agree(self, ok):
+        return all(self.all_gather(bool(ok)))
+
+    def max_float(self, x):
+        return max(self.all_gather(float(x)))
+
+    def abort(self):
+        self._s.barrier.abort()
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        if exc_type is not None:
+            self.abort()
+
+
 class Group:
     """``world`` ranks joined through rank 0's relay.  Every rank must make the same sequence of calls."""
 

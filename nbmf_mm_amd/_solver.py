@@ -68,12 +68,27 @@ def upload_any(ctx, X, mask=None, transposed=False):
 
 def nbmf_mm_solver(Y, n_components, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None,
                    H_init=None, mask=None, random_state=None, verbose=0, orientation="beta-dir",
-                   eps=1e-8, projection="normalize", device=0, _ctx_hook=None):
+                   eps=1e-8, projection="normalize", device=0, n_gpus=1, devices=None, _ctx_hook=None):
     """NBMF-MM on the GPU.  Returns ``(W (m,k), H (k,n), losses, 0.0, n_iter)``.
 
-    Mirrors src/nbmf_mm/_solver.py:61-216 argument for argument; ``projection`` and ``device``
-    are extensions.  ``time_elapsed`` is 0.0 as in the reference (:216).
+    Mirrors src/nbmf_mm/_solver.py:61-216 argument for argument; ``projection``, ``device`` and ``n_gpus`` / ``devices``
+    are extensions.  ``time_elapsed`` is 0.0 as in the reference (:216).  ``n_gpus > 1``: the same fit with the rows of
+    Y sharded over that many GPUs from this one process (``_dist.fit_in_process``: one host thread and context per GPU,
+    one exchange of the K x N H-step products per iteration); ``devices`` names the GPUs (default 0 .. n_gpus-1).
     """
+    if int(n_gpus) != 1 or devices is not None:
+        n = int(n_gpus) if devices is None else len(list(devices))
+        if devices is not None and int(n_gpus) not in (1, n):
+            raise ValueError(f"devices names {n} GPUs, n_gpus is {n_gpus}")
+        if n < 1:
+            raise ValueError("n_gpus must be >= 1")
+        if n > 1:
+            from ._dist import fit_in_process
+            return fit_in_process(Y, n_components, n, devices=devices, orientation=orientation, max_iter=max_iter, tol=tol,
+                                  alpha=alpha, beta=beta, W_init=W_init, H_init=H_init, mask=mask, random_state=random_state,
+                                  verbose=verbose, eps=eps, projection=projection)
+        if devices is not None:
+            device = int(list(devices)[0])
     proj = _projection_code(projection)
     if int(max_iter) < 1:
         raise ValueError("max_iter must be >= 1")      # the reference dies with UnboundLocalError here (:215)

@@ -534,3 +534,99 @@ def test_several_ranks_in_one_process_and_private_init_stream():
         assert out[r][0] == [0, 1, 2, 3] and out[r][1] == 3.0
         np.testing.assert_array_equal(out[r][2], W0.T / W0.T.sum(axis=0, keepdims=True))
         np.testing.assert_array_equal(out[r][3], H0)
+
+
+def _oracle_rank_fit(V_local, global_shape, offset, K, group, orientation="beta-dir", shard="rows", max_iter=500, tol=1e-5,
+                     alpha=1.2, beta=1.2, W_init=None, H_init=None, mask_local=None, random_state=None, eps=1e-8,
+                     projection="normalize", device=0, transport="auto"):
+    """What ``_dist.fit_sharded`` does for ONE rank of ``fit_in_process``, with the sharded oracle in place of the GPU:
+    same arguments, same return value ``(W (rows_here, k), H (k, cols_here), losses, n_iter)``."""
+    from nbmf_mm_amd import _dist
+    from oracle import sharded_oracle
+    M, N = global_shape
+    transposed = orientation == "dir-beta"
+    m_int, n_int = (N, M) if transposed else (M, N)
+    if transposed and W_init is not None and H_init is not None:
+        W_init, H_init = np.asarray(H_init).T, np.asarray(W_init).T
+    Wi, Hi = _dist.global_init(m_int, n_int, K, random_state, W_init, H_init)
+    V_local = np.asarray(V_local, dtype=np.float64)
+    mk = None if mask_local is None else np.asarray(mask_local, dtype=np.float64)
+    sl = slice(offset, offset + V_local.shape[0])
+
+    def allreduce(arr):
+        group.all_reduce(arr, "sum")
+
+    nobs = np.array([float(V_local.size if mk is None else np.count_nonzero(mk))])
+    allreduce(nobs)
+    if not transposed:
+        Wl, H, losses = sharded_oracle.sharded_solve(V_local, mk, Wi[:, sl], Hi, alpha, beta, nobs[0], allreduce, max_iter, tol, eps)
+        return Wl.T, H, losses, len(losses)
+    W, Hl, losses = sharded_oracle.sharded_solve_cols(V_local.T, None if mk is None else mk.T, Wi, Hi[:, sl], alpha, beta, nobs[0],
+                                                      n_int, allreduce, max_iter, tol, eps)
+    return Hl.T, W, losses, len(losses)        # un-transposed, _solver.py:178-184
+
+
+@pytest.mark.parametrize("orientation", ["beta-dir", "dir-beta"])
+@pytest.mark.parametrize("n_gpus", [2, 5])
+def test_fit_in_process_splits_seeds_and_assembles_like_the_single_fit(orientation, n_gpus):
+    """``nbmf_mm_solver(..., n_gpus=N)`` on the CPU: the entry's own logic -- ONE seeding and draw of the global generator
+    in the reference's order, row views of V and of the mask per rank, the ranks as threads over ``LocalGroup``, the split
+    factor's slices put back together, the stop rule -- with the sharded ORACLE standing in for the GPU ranks, against the
+    unsharded oracle (= the reference, tests/test_oracle_golden.py)."""
+    from nbmf_mm_amd import _dist
+    from oracle import nbmf_oracle as orc
+    M, N, K = 203, 96, 5
+    g = np.random.default_rng(17)
+    V = (g.random((M, N)) < 0.3).astype(np.float64)
+    mask = (g.random((M, N)) < 0.85)
+    for kw in (dict(max_iter=20, tol=0.0), dict(max_iter=200, tol=3e-4)):
+        W, H, losses, t, n_iter = _dist.fit_in_process(V, K, n_gpus, devices=[0] * n_gpus, orientation=orientation, alpha=1.2,
+                                                       beta=1.3, mask=mask, random_state=4, _rank_fit=_oracle_rank_fit, **kw)
+        Wr, Hr, lr, _, nr = orc.solve(V, K, alpha=1.2, beta=1.3, mask=mask.astype(np.float64), random_state=4,
+                                      orientation=orientation, **kw)
+        assert t == 0.0 and n_iter == nr == len(losses) and (kw["tol"] == 0.0 or n_iter < kw["max_iter"])
+        np.testing.assert_allclose(losses, lr, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-12)
+    # the global generator was seeded and drawn from exactly as the single fit does: what comes next is the same number
+    nxt = np.random.uniform()
+    orc.solve(V, K, max_iter=1, tol=0, random_state=4, orientation=orientation)
+    assert np.random.uniform() == nxt
+    # custom inits (both given: swapped under dir-beta, _solver.py:122-123) and a rank that fails: the error comes back,
+    # nobody hangs
+    W0, H0 = g.uniform(0.1, 0.9, (M, K)), g.uniform(0.1, 0.9, (K, N))
+    W, H, losses, _, _ = _dist.fit_in_process(V, K, n_gpus, devices=[0] * n_gpus, orientation=orientation, max_iter=6, tol=0,
+                                              W_init=W0, H_init=H0, _rank_fit=_oracle_rank_fit)
+    Wr, Hr, lr, _, _ = orc.solve(V, K, max_iter=6, tol=0, W_init=W0, H_init=H0, orientation=orientation)
+    np.testing.assert_allclose(losses, lr, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(W, Wr, rtol=0, atol=1e-12)
+
+    def failing(V_local, global_shape, offset, K, group, **kw):
+        if group.rank == n_gpus - 1:
+            raise RuntimeError("rank down")
+        return _oracle_rank_fit(V_local, global_shape, offset, K, group, **kw)
+    with pytest.raises(RuntimeError, match="rank down"):
+        _dist.fit_in_process(V, K, n_gpus, devices=[0] * n_gpus, orientation=orientation, max_iter=5, tol=0, _rank_fit=failing)
+    with pytest.raises(ValueError, match="devices names"):
+        _dist.fit_in_process(V, K, n_gpus, devices=[0], _rank_fit=_oracle_rank_fit)
+
+
+def test_local_group_collectives():
+    import threading
+    from nbmf_mm_amd import _rendezvous
+    groups = _rendezvous.LocalGroup.make(4)
+    out = [None] * 4
+
+    def body(r):
+        g = groups[r]
+        a = np.full(3, float(r + 1))
+        g.all_reduce(a, "sum")
+        out[r] = (g.all_gather(r * 10), g.broadcast("x" if r == 2 else None, src=2), g.agree(r != 1), g.agree(True),
+                  g.max_float(r * 0.5), a.tolist())
+        g.barrier()
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    assert all(o == ([0, 10, 20, 30], "x", False, True, 1.5, [10.0, 10.0, 10.0]) for o in out)

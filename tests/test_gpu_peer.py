@@ -308,3 +308,74 @@ def test_bench_is_bounded_when_the_peer_transport_attaches_nowhere():
     assert not line["config"]["transport"].startswith("peer")          # the faulty transport was not chosen
     assert "peer" not in (line["config"]["transport_trials_s_per_5_iterations"] or {})
     assert wall < 90.0, f"transport selection with a dead peer transport took {wall:.0f} s"
+
+
+_N_GPUS_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from nbmf_mm_amd import NBMF, nbmf_mm_solver, _hip
+g = np.random.default_rng(31)
+M, N, K = 2100, 640, 64
+X = (g.random((M, N)) < 0.3).astype(np.float64)
+mask = g.random((M, N)) < 0.9
+out = {}
+for orientation in ("beta-dir", "dir-beta"):
+    for name, kw in (("tol0", dict(max_iter=12, tol=0.0)), ("stop", dict(max_iter=300, tol=2e-4))):
+        one = NBMF(n_components=K, random_state=2, orientation=orientation, alpha=1.2, beta=1.3, **kw).fit(X, mask=mask)
+        nxt1 = np.random.uniform()
+        many = NBMF(n_components=K, random_state=2, orientation=orientation, alpha=1.2, beta=1.3, n_gpus=8, devices=[0] * 8,
+                    **kw).fit(X, mask=mask)
+        nxt8 = np.random.uniform()
+        l1, l8 = np.array(one.loss_curve_), np.array(many.loss_curve_)
+        out[orientation + "/" + name] = dict(
+            n_iter=(int(one.n_iter_), int(many.n_iter_)), max_iter=kw["max_iter"],
+            loss=float(np.max(np.abs(l1 - l8) / np.abs(l1))) if len(l1) == len(l8) else None,
+            W=float(np.abs(one.W_ - many.W_).max()), H=float(np.abs(one.components_ - many.components_).max()),
+            shapes=[list(many.W_.shape), list(many.components_.shape)], rng=(nxt1 == nxt8))
+    # the function entry, uint8 data, normalised alias: the same fit once more
+    W, H, losses, t, n_it = nbmf_mm_solver(X.astype(np.uint8), K, max_iter=5, tol=0, random_state=2, mask=mask,
+                                           orientation=orientation, alpha=1.2, beta=1.3, n_gpus=8, devices=[0] * 8)
+    ref = nbmf_mm_solver(X, K, max_iter=5, tol=0, random_state=2, mask=mask, orientation=orientation, alpha=1.2, beta=1.3)
+    out[orientation + "/solver"] = dict(t=t, n_iter=n_it, loss=float(np.max(np.abs(np.array(losses) - np.array(ref[2])) / np.abs(ref[2]))),
+                                        W=float(np.abs(W - ref[0]).max()), H=float(np.abs(H - ref[1]).max()))
+try:
+    NBMF(n_components=K, n_gpus=3, devices=[0, 0]).fit(X)
+    out["bad_devices"] = "no error"
+except ValueError as e:
+    out["bad_devices"] = str(e)
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_n_gpus_behind_the_drop_in_api_eight_ranks_in_one_process():
+    """``NBMF(n_components=64, n_gpus=8)``: the sharded fit behind the reference's own estimator API, ONE process -- eight
+    rank threads, a context and stream each, the peer transport addressing the other ranks' arenas directly (same
+    process: no IPC).  All eight ranks on device 0 here (the box has one GPU; `devices=[0] * 8`), which needs hardware
+    queues of their own for the ranks' streams -- hence the child process with GPU_MAX_HW_QUEUES set before HIP starts.
+    Against ``n_gpus=1``: loss curves, W_ and components_ to 1e-12, both orientations (rows of V = rows, or columns, of
+    the internal matrix), the stop rule firing at the same iteration, and the global generator left in the same state.
+    NOT measured across physical devices (no multi-GPU machine in reach)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", NBMF_PERSISTENT="0", NBMF_PEER_TIMEOUT_MS="20000")
+    r = subprocess.run([sys.executable, "-c", _N_GPUS_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    for orientation in ("beta-dir", "dir-beta"):
+        for name in ("tol0", "stop"):
+            o = out[f"{orientation}/{name}"]
+            assert o["n_iter"][0] == o["n_iter"][1], o
+            assert (name == "tol0") == (o["n_iter"][0] == o["max_iter"]), o       # the stop rule fired in the "stop" runs
+            assert o["loss"] is not None and o["loss"] <= 1e-12 and o["W"] <= 1e-12 and o["H"] <= 1e-12, o
+            assert o["shapes"] == [[2100, 64], [64, 640]] and o["rng"] is True
+        o = out[f"{orientation}/solver"]
+        assert o["t"] == 0.0 and o["n_iter"] == 5 and o["loss"] <= 1e-12 and o["W"] <= 1e-12 and o["H"] <= 1e-12, o
+    assert "devices names 2 GPUs" in out["bad_devices"]
+    # without the hardware queues the entry refuses instead of risking ranks that wait for each other on one queue
+    from nbmf_mm_amd import _dist
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
+        with pytest.raises(ValueError, match="GPU_MAX_HW_QUEUES"):
+            _dist.fit_in_process(np.zeros((64, 32)), 4, 8, devices=[0] * 8, max_iter=1)
