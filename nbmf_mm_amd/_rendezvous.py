@@ -474,6 +474,15 @@ class Group:
                 # bytes on undecoded -- b"t" + count(2) + b"s" + len + tag ...
                 if any(not f.startswith(_MSG_PREFIX) for f in frames):
                     break            # a ("bye", None) envelope (or anything that is not a message): the group ends
+                # Every frame must be a well-formed message before it is spliced into what ALL ranks receive: a
+                # malformed one would otherwise surface as a decode error on every rank.  (Decoding executes nothing;
+                # the relay still forwards the bytes it was given.)  A rank that sends garbage is treated as a rank
+                # that died: the group ends, the others see their sockets close.
+                for r, f in enumerate(frames):
+                    try:
+                        decode(f)
+                    except Exception as e:
+                        raise ConnectionError(f"rank {r} sent a malformed frame: {e}") from None
                 body = b"l" + _HDR.pack(len(frames)) + b"".join(f[_ENV_SKIP:] for f in frames)
                 out = _HDR.pack(len(body)) + body
                 for c in conns:

@@ -653,7 +653,14 @@ void stream_release(int device, hipStream_t st) {   // the caller has synchronis
 // shows the same 35.0 ms on the device for a 3000-iteration fit whether the host saw 35.2 or 43.7 ms -- what round 2
 // took for a second, slower "speed" of the single-launch path).  For a fit that lasts 3 ms that is the run three times
 // over, so the small-problem paths poll the stream for up to `spin_ms` before they fall back to the blocking call.
-hipError_t stream_wait_spin(hipStream_t st, double spin_ms = 200.0) {
+hipError_t stream_wait_spin(hipStream_t st, double spin_ms = -1.0) {
+  // (the budget: 200 ms unless NBMF_SPIN_MS says otherwise -- a host whose cores are shared by many rank threads may
+  //  prefer to sleep at once: NBMF_SPIN_MS=0)
+  static const double spin_default = [] {
+    const char* e = getenv("NBMF_SPIN_MS");
+    return e ? std::max(0.0, atof(e)) : 200.0;
+  }();
+  if (spin_ms < 0.0) spin_ms = spin_default;
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     const hipError_t e = hipStreamQuery(st);
@@ -734,9 +741,26 @@ constexpr int kNcclSum = 0;       // ncclSum
 // lands on the same address handed the peers a mapping of the OLD memory (seen as a wrong factor in the second
 // of two sharded fits in one process); a handle that stays valid for good cannot go stale.
 struct PeerOrigin {   // tail of a handle block
-  unsigned long long pid, arena, flags;
-  int device, reserved;
+  unsigned long long pid, arena, flags;   // pid: not the process id (two containers of a node may both run a pid 1) but a
+  int device, reserved;                   // 64-bit number drawn once per process: process_nonce()
 };
+// Who exported a handle block: a rank of THIS process is addressed through the exporter's own pointers, so "this
+// process" must not be decided by something two processes can share.  Process ids are unique per PID namespace only;
+// a random 64-bit number drawn once at first use (mixed with the pid and the clock in case the random device is a
+// constant) is unique for practical purposes.
+unsigned long long process_nonce() {
+  static const unsigned long long nonce = [] {
+    unsigned long long v = 0;
+    if (FILE* f = fopen("/dev/urandom", "rb")) {
+      if (fread(&v, sizeof v, 1, f) != 1) v = 0;
+      fclose(f);
+    }
+    v ^= (unsigned long long)getpid() * 0x9E3779B97F4A7C15ull;
+    v ^= (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 0xBF58476D1CE4E5B9ull;
+    return v ? v : 1ull;
+  }();
+  return nonce;
+}
 struct ArenaSlot {
   int device;
   size_t doubles;
@@ -778,7 +802,7 @@ int arena_acquire(int device, size_t doubles, ArenaSlot** out) {
     static_assert(2 * sizeof(hipIpcMemHandle_t) + sizeof(PeerOrigin) <= NBMF_PEER_HANDLE_BYTES, "handle block too small");
     memset(a->handles, 0, sizeof a->handles);
     memcpy(a->handles, h, sizeof h);
-    const PeerOrigin origin{(unsigned long long)getpid(), (unsigned long long)a->arena, (unsigned long long)a->flags, device, 0};
+    const PeerOrigin origin{process_nonce(), (unsigned long long)a->arena, (unsigned long long)a->flags, device, 0};
     memcpy(a->handles + sizeof h, &origin, sizeof origin);
     g_arenas.push_back(a);
     best = a;
@@ -1114,6 +1138,18 @@ inline int wg_strips(const nbmf_ctx* c) { return WG_WAVES * pass_ns(c->KS > 1 ? 
 // 0 <= Theta < 1 -- true throughout a fit that starts from factors in range (W on the simplex, H <= 1 - eps stay so) and
 // eps >= 1e-12 (so that 1 - eps is below 1).  Anything else -- H_init above 1, negative entries, a tiny eps -- takes the
 // TINY variant, whose selects follow `_solver.py:42-43` for any Theta.
+// Which variant of the sweeps a run takes.  The plain variant (TINY = false) forms |Theta - z| for the denominators,
+// shares one reciprocal among a lane's entries and renormalises the likelihood's product once per trip; all of that is
+// the reference's arithmetic bit for bit (binary path) or to rounding (general path) ONLY under these invariants:
+//   eps >= 1e-12            (1 - eps < 1 in double; sixteen factors >= eps stay above 1e-192; products of four or eight
+//                            denominators cannot underflow),
+//   W >= 0 with column sums <= 1 + 1e-12  and  0 <= H <= 1 - 1e-9   when the factors were set (factors_in_range, checked
+//                            on the device by nbmf_set_factors): then 0 <= Theta < 1 for the whole fit -- the W-update
+//                            renormalises or projects onto the simplex, the H-update clips to [eps, 1 - eps].
+// Anything else -- H_init above 1 (the reference uses it as given, _solver.py:133), negative entries, transform's
+// un-normalised start (_base.py:175: w_free), a tiny eps -- takes the TINY variant, which keeps the reference's own
+// selects, one reciprocal per entry and a renormalisation per entry
+// (tests: test_factors_out_of_the_fits_range_follow_the_reference).
 int tiny_a(const nbmf_ctx* c) { return c->eps < 1e-70 || (NBMF_ZTRICK && !(c->eps >= 1e-12 && c->factors_in_range)); }
 
 double ll_pad_of(const nbmf_ctx* c, int strict = 0) {
@@ -3230,7 +3266,7 @@ int nbmf_comm_init_peer(nbmf_ctx* c, const void* handles, int nranks, int rank, 
     PeerOrigin origin;
     memcpy(h, (const char*)handles + (size_t)j * NBMF_PEER_HANDLE_BYTES, sizeof h);
     memcpy(&origin, (const char*)handles + (size_t)j * NBMF_PEER_HANDLE_BYTES + sizeof h, sizeof origin);
-    if (origin.pid == (unsigned long long)getpid()) {
+    if (origin.pid == process_nonce()) {
       // a rank of THIS process (several contexts, one host thread each): its arena is plain device memory here;
       // if it lives on another GPU of this process, peer access makes it addressable (pooled arenas are never freed,
       // so the address stays valid for the life of the process)
