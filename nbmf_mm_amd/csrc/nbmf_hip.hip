@@ -107,6 +107,9 @@
 #ifndef NBMF_GEN_H_WGS
 #define NBMF_GEN_H_WGS 2   // general path, H sweep at K <= 64: workgroups per CU the kernel is compiled for (3 needs <= 168 registers)
 #endif
+#ifndef NBMF_EVEN_PLACEMENT
+#define NBMF_EVEN_PLACEMENT 0   // 1 = single-round sweeps ask for as much LDS as makes every CU take the same number of workgroups (launch_pass_tt); measured in round 4: the dispatcher already places them evenly (256 workgroups in each wave slot at configs[1]), no change
+#endif
 #ifndef NBMF_NO_MFMA
 #define NBMF_NO_MFMA 0   // 1 = measurement build: the sweeps without their MFMAs (see NBMF_MFMA in nbmf_pass_kernel.inc)
 #endif
@@ -426,6 +429,7 @@ struct nbmf_ctx {
   int chunksH = 0, CH_H = 0, chunksW = 0, CH_W = 0;
   int *cstartH = nullptr, *cstartW = nullptr;   // device: chunk boundaries of the two sweeps
   double *slabH = nullptr, *slabW = nullptr, *Pbuf = nullptr, *lossbuf = nullptr, *prior = nullptr, *scal = nullptr;
+  double* lossfin = nullptr;   // the slots of the fused loss assembly (PassFin): LL_EMPTY in every slot between sweeps
   int n_prior_blocks = 0;
   int* flags = nullptr;
   double* losses_d = nullptr;
@@ -862,17 +866,92 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   PassArgs a = a_;
+  // (NBMF_EVEN_PLACEMENT, off: a sweep that fits the chip in ONE round with room to spare -- configs[1]: 1024 workgroups,
+  //  four per CU, where LDS and registers would admit five -- asks for as much LDS per workgroup as leaves room for exactly
+  //  ceil(workgroups / CUs) of them per CU.  Built on the suspicion that the dispatcher fills some CUs with five and some
+  //  with three; NBMF_PASS_TRACE showed it does not -- 256 workgroups in each of the wave slots 0..3 -- and the spread of
+  //  the workgroups' finishing times is the SIMD arbiter's: oldest wave first, slot 0 done after 168 us, slot 3 after 217.)
+  int lds_ask = lds_bytes;
+  if (NBMF_EVEN_PLACEMENT) {
+    int dev = 0;
+    DevInfo di;
+    if (hipGetDevice(&dev) == hipSuccess && device_info(dev, &di) == hipSuccess && di.cus > 0) {
+      const long long n_wg = (long long)grid.x * grid.y;
+      const long long per_cu = (n_wg + di.cus - 1) / di.cus;
+      if (n_wg >= di.cus && per_cu >= 2) {
+        const int even = (int)((160 * 1024 / per_cu) & ~255ll);
+        if (even > lds_ask && even <= 65536) lds_ask = even;
+      }
+    }
+  }
   if (DATA != DATA_BIN && MODE != MODE_W && MODE != MODE_T && pass_log_bits(KB) == 10) {
     hipError_t e = log_table_device(&a.ltab_g);
     if (e != hipSuccess) return e;
   }
+  if (getenv("NBMF_PASS_TRACE") && MODE != MODE_T) {
+    // diagnosis: where the workgroups of THIS launch spend their time outside the loop.  Every workgroup notes the wall
+    // clock (100 MHz) at entry, at the top of its loop, at the loop's end and at exit; printed: the launch's span, the
+    // spread of the entries and exits, mean prologue / loop / epilogue.  Serialises the stream (one launch at a time).
+    const size_t n_wg = (size_t)grid.x * grid.y;
+    unsigned long long* tr = nullptr;
+    hipError_t e = dmalloc(&tr, sizeof(unsigned long long) * 5 * n_wg);
+    if (e != hipSuccess) return e;
+    a.trace = tr;
+    hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_ask, st, a);
+    std::vector<unsigned long long> h(5 * n_wg);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), tr, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+    dfree(tr);
+    if (e != hipSuccess) return e;
+    unsigned long long t_first = ~0ull, t_last = 0, last_entry = 0, first_exit = ~0ull;
+    double pro = 0, loop = 0, epi = 0;
+    std::vector<double> exits;
+    size_t live = 0;
+    for (size_t i = 0; i < n_wg; ++i) {
+      const unsigned long long* t = h.data() + 5 * i;
+      if (!t[3]) continue;
+      ++live;
+      t_first = std::min(t_first, t[0]);
+      t_last = std::max(t_last, t[3]);
+      last_entry = std::max(last_entry, t[0]);
+      first_exit = std::min(first_exit, t[3]);
+      pro += (double)(t[1] - t[0]);
+      loop += (double)(t[2] - t[1]);
+      epi += (double)(t[3] - t[2]);
+      exits.push_back((double)t[3]);
+    }
+    if (live) {
+      // mean time from entry to exit by the wave slot (HW_ID bits 3:0) the workgroup's first wave was given: does the
+      // SIMD's arbiter favour some slots (oldest first)?
+      double dur[16] = {0};
+      int cnt[16] = {0};
+      for (size_t i = 0; i < n_wg; ++i) {
+        const unsigned long long* t = h.data() + 5 * i;
+        if (!t[3]) continue;
+        dur[t[4] & 15] += (double)(t[3] - t[0]);
+        ++cnt[t[4] & 15];
+      }
+      fprintf(stderr, "[nbmf]   mean entry-to-exit by wave slot:");
+      for (int w = 0; w < 16; ++w)
+        if (cnt[w]) fprintf(stderr, " slot %d: %.1f us (%d)", w, dur[w] / cnt[w] * 0.01, cnt[w]);
+      fprintf(stderr, "\n");
+      std::sort(exits.begin(), exits.end());
+      const double us = 0.01;   // 100 MHz ticks
+      fprintf(stderr, "[nbmf] pass<K=%d,data=%d,mode=%d> %zu workgroups: span %.1f us | entries spread over %.1f us | exits: first %.1f, median %.1f, "
+                      "last %.1f us before the end | per workgroup: prologue %.2f, loop %.2f, epilogue %.2f us\n", 16 * KB, DATA, MODE, live,
+              (double)(t_last - t_first) * us, (double)(last_entry - t_first) * us, (double)(t_last - first_exit) * us,
+              ((double)t_last - exits[exits.size() / 2]) * us, 0.0, pro / live * us, loop / live * us, epi / live * us);
+    }
+    return hipSuccess;
+  }
   if (tl_attach_start) {
     hipEvent_t e0 = tl_attach_start, e1 = tl_attach_stop;
     tl_attach_start = tl_attach_stop = nullptr;
-    hipExtLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, e0, e1, 0, a);
+    hipExtLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_ask, st, e0, e1, 0, a);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
+  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_ask, st, a);
   return hipGetLastError();
 }
 // (eps below 1e-70 on the binary path: the variant with per-entry reciprocals and renormalisation, see pass_kernel)
@@ -1253,9 +1332,23 @@ int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int cli
 }
 
 // Single GPU, one slice: the sweep that scores iteration t assembles its loss itself (PassFin: no finalize launch).
+// every slot of the fused loss assembly empty (PassFin): at set-up, and whenever a sweep may have left some filled
+// (a run that was interrupted by an error)
+__global__ void fill_u64_kernel(unsigned long long* p, size_t n, unsigned long long v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int fill_ll_empty(nbmf_ctx* c) {
+  const size_t n = (size_t)c->chunksH * (c->nA / 16 / WG_WAVES);
+  if (!c->lossfin || !n) return NBMF_OK;
+  hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (unsigned long long*)c->lossfin, n, LL_EMPTY);
+  HIPCHK(hipGetLastError());
+  return NBMF_OK;
+}
 bool fin_fusable(const nbmf_ctx* c) { return !is_sharded(c) && c->KS == 1 && !getenv("NBMF_NO_FUSED_FINALIZE"); }
 void fin_fill(nbmf_ctx* c, PassArgs& a, int t, double tol, int strict) {
   a.fin.on = 1;
+  a.lossbuf = c->lossfin;   // (the sweep's workgroups hand their partials in here; see PassFin)
   a.fin.t = t;
   a.fin.n_ll = c->chunksH * (int)(c->nA / 16 / wg_strips(c));
   a.fin.n_prior = c->n_prior_src;
@@ -2278,7 +2371,7 @@ int setup_workspaces(nbmf_ctx* c) {
   if (getenv("NBMF_DEBUG"))
     fprintf(stderr, "[nbmf] K_pad=%d path=%d: H-pass %d x %d workgroups (chunk %d blocks, %d slots), W-pass %d x %d (chunk %d, %d slots)\n",
             c->KP, c->data_kind, (int)(c->nA / 64), c->chunksH, c->CH_H, slotsH, (int)(c->mA / 64), c->chunksW, c->CH_W, slotsW);
-  for (double** p : {&c->slabH, &c->slabW, &c->lossbuf}) {
+  for (double** p : {&c->slabH, &c->slabW, &c->lossbuf, &c->lossfin}) {
     if (*p) HIPCHK(dfree(*p));
     *p = nullptr;
   }
@@ -2300,7 +2393,10 @@ int setup_workspaces(nbmf_ctx* c) {
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
   HIPCHK(dmalloc(&c->slabH, 2 * (size_t)c->chunksH * fh));
   HIPCHK(dmalloc(&c->slabW, (size_t)c->chunksW * fw));
-  HIPCHK(dmalloc(&c->lossbuf, sizeof(double) * (size_t)c->chunksH * (c->nA / 16 / WG_WAVES)));
+  const size_t n_slots = (size_t)c->chunksH * (c->nA / 16 / WG_WAVES);
+  HIPCHK(dmalloc(&c->lossbuf, sizeof(double) * n_slots));
+  HIPCHK(dmalloc(&c->lossfin, sizeof(double) * n_slots));
+  if (int rc = fill_ll_empty(c)) return rc;
   return NBMF_OK;
 }
 
@@ -2453,7 +2549,7 @@ int nbmf_destroy(nbmf_ctx* c) {
   if (c->host_buf) hipHostFree(c->host_buf);
   arena_release((ArenaSlot*)c->arena_slot.p);   // back to the pool, never to the allocator (see ArenaSlot)
   void* ptrs[] = {c->dataA, c->dataB, c->maskA, c->maskB, c->rowcnt, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG,
-                  c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
+                  c->slabH, c->slabW, c->Pbuf, c->lossbuf, c->lossfin, c->prior, c->scal, c->flags, c->losses_d, c->stage, c->stats,
                   c->sbuf, c->Qbuf, c->cstartH, c->cstartW, c->theta, c->small.slab, c->small_batch.slab, c->small_batch.table,
                   c->small_batch.io, c->bitsA, c->bitsB};
   for (void* p : ptrs)

@@ -63,6 +63,17 @@ def test_the_shipped_library_passes_and_a_seeded_violation_fails_the_build(tmp_p
     isa = os.path.join(ROOT, "build", "nbmf_hip.isa.s")
     n, bad, sbad = _checker().check(isa, check_sgpr=True, verbose=False)
     assert n > 2000 and (bad, sbad) == (0, 0)
+    # two more properties of the ISA the sources rely on:
+    text = open(isa).read()
+    import re
+    # (1) the sweeps have NO static LDS, so their dynamic region starts at address 0 and the general path's table is
+    #     gathered with an immediate offset (pass_kernel: LTAB_BYTE; it also returns at once if this ever changed)
+    sizes = re.findall(r"\.amdhsa_kernel (\S*pass_kernel\S*)\n(?:.*\n)*?\s*\.amdhsa_group_segment_fixed_size (\d+)", text)
+    assert len(sizes) > 60 and all(int(b) == 0 for _, b in sizes), [s_ for s_ in sizes if int(s_[1])][:3]
+    # (2) the peak self-test's MFMAs are the VGPR form (bench.py's roofline.peak_measured would read ~8 % low otherwise)
+    body = text[text.index("mfma_peak_kernelEPdidd:"):]
+    body = body[:body.index(".Lfunc_end")]
+    assert body.count("v_mfma_f64_16x16x4_f64 v[") >= 8 and "a[" not in body and "accvgpr" not in body
     # the same sources with one deliberately unprotected MFMA compiled in: make must fail and leave no library behind
     out = str(tmp_path / "libseed.so")
     flags = "-O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-value -Wno-unused-result -DNBMF_HAZARD_SEED=1"
