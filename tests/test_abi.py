@@ -86,3 +86,28 @@ def test_header_compiles_as_c99_and_links():
     if _hip.device_count() == 0:
         out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
         assert out.returncode == 3 and "no GPU" in out.stderr      # fails loudly without a device
+
+
+def test_cpu_reachable_paths_under_host_asan():
+    """SURVEY section 5 (sanitizers): the library built with AddressSanitizer on the host side (`make asan`; device code as
+    usual) and every entry point of the ABI called with null pointers and zero sizes in a child process that preloads the
+    ASan runtime (tests/asan_null_calls.py): error codes, no fault, no ASan report.  What a host without a GPU can reach of
+    the C layer: argument validation, the error plumbing and its thread-local message."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not hipcc or not os.path.exists(clang):
+        pytest.skip("needs hipcc and its clang")
+    rt = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(rt):
+        pytest.skip("no AddressSanitizer runtime beside the compiler")
+    mk = subprocess.run(["make", "-C", os.path.join(ROOT, "nbmf_mm_amd", "csrc"), "asan"], capture_output=True, text=True)
+    assert mk.returncode == 0, (mk.stdout + mk.stderr)[-2000:]
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               NBMF_HIP_LIBRARY=os.path.join(ROOT, "build", "libnbmf_hip_asan.so"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_null_calls.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "ASAN_NULL_CALLS_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    assert "AddressSanitizer" not in r.stderr
