@@ -107,6 +107,9 @@
 #ifndef NBMF_GEN_H_WGS
 #define NBMF_GEN_H_WGS 2   // general path, H sweep at K <= 64: workgroups per CU the kernel is compiled for (3 needs <= 168 registers)
 #endif
+#ifndef NBMF_FAIR_PRIO
+#define NBMF_FAIR_PRIO 0   // 1 = experiment: issue priorities of the workgroups that share a CU rotate trip by trip (pass_kernel)
+#endif
 #ifndef NBMF_EVEN_PLACEMENT
 #define NBMF_EVEN_PLACEMENT 0   // 1 = single-round sweeps ask for as much LDS as makes every CU take the same number of workgroups (launch_pass_tt); measured in round 4: the dispatcher already places them evenly (256 workgroups in each wave slot at configs[1]), no change
 #endif
@@ -871,6 +874,23 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
   //  ceil(workgroups / CUs) of them per CU.  Built on the suspicion that the dispatcher fills some CUs with five and some
   //  with three; NBMF_PASS_TRACE showed it does not -- 256 workgroups in each of the wave slots 0..3 -- and the spread of
   //  the workgroups' finishing times is the SIMD arbiter's: oldest wave first, slot 0 done after 168 us, slot 3 after 217.)
+  if (NBMF_FAIR_PRIO && MODE != MODE_T) {
+    static int resident = -1;   // (per instantiation)
+    if (resident < 0) {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)pass_kernel<KB, DATA, MODE, TH, TINY>, 64 * WG_WAVES, lds_bytes) != hipSuccess) n = 0;
+      resident = n;
+    }
+    int dev = 0;
+    DevInfo di;
+    if (resident > 0 && hipGetDevice(&dev) == hipSuccess && device_info(dev, &di) == hipSuccess && di.cus > 0) {
+      const long long n_wg = (long long)grid.x * grid.y;
+      const long long here = std::min<long long>(resident, (n_wg + di.cus - 1) / di.cus);
+      const char* e = getenv("NBMF_FAIR_ROUNDS");   // 1 (default): one-round sweeps only; 0: every sweep
+      const bool one_round = n_wg <= (long long)di.cus * resident;
+      if (here >= 2 && here <= 4 && (one_round || (e && atoi(e) == 0))) a.fair_mod = (int)here;
+    }
+  }
   int lds_ask = lds_bytes;
   if (NBMF_EVEN_PLACEMENT) {
     int dev = 0;
