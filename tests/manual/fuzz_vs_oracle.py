@@ -51,8 +51,12 @@ def run(cases, seed, max_dim=700):
         duchi = bool(r.random() < 0.25) and init in ("seed", "in_range")   # (the extension: Euclidean projection, README.md:27-35)
         with np.errstate(all="ignore"):
             Wr, Hr, lr, _, _ = orc.solve(Y, k, step=orc.mm_step_duchi if duchi else None, **kw)
+        # (round 4: binary data is handed over as bool / uint8 in a third of the cases -- one byte per entry, nbmf_upload_v)
+        Y_in = Y
+        if not real:
+            Y_in = {0: Y, 1: Y.astype(np.uint8), 2: Y.astype(bool)}[int(r.integers(0, 3))]
         try:
-            W, H, l, _, _ = nbmf_mm_solver(Y, k, projection="duchi" if duchi else "normalize", **kw)
+            W, H, l, _, _ = nbmf_mm_solver(Y_in, k, projection="duchi" if duchi else "normalize", **kw)
         except Exception as e:   # noqa: BLE001
             bad += 1
             print(f"case {case}: EXCEPTION {e!r}  m={m} n={n} k={k} real={real} mask={mk} init={init} eps={eps_kind} {kw['orientation']}")
