@@ -505,6 +505,50 @@ def test_perplexity_grid_matches_reference_driver(hip):
     assert abs(got - want) <= 1e-12 * want
 
 
+@pytest.mark.parametrize("k", [5, 24, 40, 100])
+@pytest.mark.parametrize("masked", [False, True])
+def test_real_valued_data_with_a_binary_mask_every_sweep_variant(hip, k, masked):
+    """The 8-byte storage path whose mask (if any) is folded into the data (DATA_F64): image A keeps an unobserved entry as
+    -0.0, so the strictly masked likelihood tells "unobserved" from an OBSERVED zero by the sign bit -- checked here with
+    exact zeros (+0.0 and -0.0) among the observed data.  Every sweep variant against the oracle: the fit (H, W and
+    likelihood sweeps), nbmf_loss, nbmf_loglik with and without clipping, nbmf_loglik_strict; K = 5 / 24 / 40 / 100 are
+    the four register layouts (the last one with the 256-entry logarithm table)."""
+    r = np.random.default_rng(100 + k)
+    m, n = 77, 150
+    Y = r.random((m, n))
+    Y[r.random((m, n)) < 0.1] = 0.0                      # observed exact zeros ...
+    Y[3, 5], Y[4, 6] = -0.0, 1.0                         # ... one of them negative zero; an exact one
+    mask = (r.random((m, n)) < 0.8) if masked else None
+    if masked:
+        mask[3, 5] = mask[4, 6] = True
+    from nbmf_mm_amd import nbmf_mm_solver
+    W, H, l, _, _ = nbmf_mm_solver(Y, k, max_iter=8, tol=0, random_state=3, mask=mask, alpha=1.3, beta=1.1)
+    Wr, Hr, lr, _, _ = orc.solve(Y, k, max_iter=8, tol=0, random_state=3, mask=mask, alpha=1.3, beta=1.1)
+    np.testing.assert_allclose(l, lr, rtol=LOSS_RTOL, atol=0)
+    np.testing.assert_allclose(W, Wr, rtol=0, atol=FACTOR_ATOL)
+    np.testing.assert_allclose(H, Hr, rtol=0, atol=FACTOR_ATOL)
+    mf = None if mask is None else mask.astype(np.float64)
+    with hip.Context(m, n, k) as ctx:
+        ctx.set_hyper(1.3, 1.1)
+        assert ctx.upload(Y, mask=mask) is False          # doubles, not byte codes
+        ctx.set_factors(np.ascontiguousarray(Wr.T), Hr)
+        want = orc.mm_loss(Y, Wr.T, Hr, mf, 1.3, 1.1)
+        assert abs(ctx.loss() - want) <= 1e-12 * abs(want)
+        want = orc.score(Y, Wr, Hr, mf)
+        assert abs(ctx.loglik(clip_theta=True) / ctx.n_obs() - want) <= 1e-12 * abs(want)
+        assert abs(ctx.loglik() / ctx.n_obs() - want) <= 1e-12 * abs(want)      # (W @ H <= 1 here: clipping changes nothing)
+        want = orc.heldout_perplexity(Y, Wr @ Hr, mf)
+        got = np.exp(-ctx.loglik_strict() / ctx.n_obs())
+        assert abs(got - want) <= 1e-12 * want
+        assert ctx.n_obs() == (m * n if mask is None else np.count_nonzero(mask))
+        # factors pushed off the simplex by hand (W @ H above 1 in places): the clipped sweep is the reference's score
+        # (_base.py:210: clip first, then the logarithms)
+        Hbig = np.clip(Hr * 3.0, 0, None)
+        ctx.set_factors(np.ascontiguousarray(Wr.T), Hbig)
+        want = orc.score(Y, Wr, Hbig, mf)
+        assert (Wr @ Hbig).max() > 1.0 and abs(ctx.loglik(clip_theta=True) / ctx.n_obs() - want) <= 1e-12 * abs(want)
+
+
 def _vs_oracle(Y, k, mask=None, iters=15, **kw):
     from nbmf_mm_amd import nbmf_mm_solver
     W, H, l, _, n1 = nbmf_mm_solver(Y, k, max_iter=iters, tol=0, mask=mask, **kw)
