@@ -339,6 +339,19 @@ for orientation in ("beta-dir", "dir-beta"):
     ref = nbmf_mm_solver(X, K, max_iter=5, tol=0, random_state=2, mask=mask, orientation=orientation, alpha=1.2, beta=1.3)
     out[orientation + "/solver"] = dict(t=t, n_iter=n_it, loss=float(np.max(np.abs(np.array(losses) - np.array(ref[2])) / np.abs(ref[2]))),
                                         W=float(np.abs(W - ref[0]).max()), H=float(np.abs(H - ref[1]).max()))
+# other storage paths through the same entry: real-valued data with real weights (16 bytes per entry), with a bool mask
+# (8 bytes, mask folded in), and a scipy CSR matrix with a CSR pattern mask (never densified; sliced by rows per rank)
+import scipy.sparse as sp
+Xr, wts = g.random((900, 300)), g.random((900, 300))
+mb = g.random((900, 300)) < 0.85
+Xs = sp.csr_matrix((g.random((900, 300)) < 0.1).astype(np.float64))
+for name, data, mk in (("weights", Xr, wts), ("folded", Xr, mb), ("csr", Xs, sp.csr_matrix(mb.astype(np.float64)))):
+    kw = dict(n_components=24, random_state=5, max_iter=10, tol=0.0, orientation="dir-beta" if name == "folded" else "beta-dir")
+    one = NBMF(**kw).fit(data, mask=mk)
+    many = NBMF(n_gpus=4, devices=[0] * 4, **kw).fit(data, mask=mk)
+    l1, l4 = np.array(one.loss_curve_), np.array(many.loss_curve_)
+    out["paths/" + name] = dict(loss=float(np.max(np.abs(l1 - l4) / np.abs(l1))), W=float(np.abs(one.W_ - many.W_).max()),
+                                H=float(np.abs(one.components_ - many.components_).max()))
 try:
     NBMF(n_components=K, n_gpus=3, devices=[0, 0]).fit(X)
     out["bad_devices"] = "no error"
@@ -373,6 +386,9 @@ def test_n_gpus_behind_the_drop_in_api_eight_ranks_in_one_process():
             assert o["shapes"] == [[2100, 64], [64, 640]] and o["rng"] is True
         o = out[f"{orientation}/solver"]
         assert o["t"] == 0.0 and o["n_iter"] == 5 and o["loss"] <= 1e-12 and o["W"] <= 1e-12 and o["H"] <= 1e-12, o
+    for name in ("weights", "folded", "csr"):
+        o = out["paths/" + name]
+        assert o["loss"] <= 1e-12 and o["W"] <= 1e-12 and o["H"] <= 1e-12, (name, o)
     assert "devices names 2 GPUs" in out["bad_devices"]
     # without the hardware queues the entry refuses instead of risking ranks that wait for each other on one queue
     from nbmf_mm_amd import _dist
