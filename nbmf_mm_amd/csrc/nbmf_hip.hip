@@ -1372,6 +1372,12 @@ int fill_ll_empty(nbmf_ctx* c) {
 bool fin_fusable(const nbmf_ctx* c) { return !is_sharded(c) && c->KS == 1 && !getenv("NBMF_NO_FUSED_FINALIZE"); }
 void fin_fill(nbmf_ctx* c, PassArgs& a, int t, double tol, int strict) {
   a.fin.on = 1;
+  a.fin.wait_ticks = LL_WAIT_TICKS;
+  if (const char* e = getenv("NBMF_PASSFIN_FAULT"))   // tests: one workgroup withholds its partial, the wait is short
+    if (atoi(e) != 0) {
+      a.fin.on = 2;
+      a.fin.wait_ticks = 20000000ull;   // 0.2 s
+    }
   a.lossbuf = c->lossfin;   // (the sweep's workgroups hand their partials in here; see PassFin)
   a.fin.t = t;
   a.fin.n_ll = c->chunksH * (int)(c->nA / 16 / wg_strips(c));
@@ -3046,11 +3052,16 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
       if (int rc = enqueue_finalize(c, use_graph ? -1 : max_iter - 1, tol)) return rc;
     }
   }
-  int fl[2];
+  int fl[8];
   HIPCHK(hipMemcpyAsync(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->timing) timing_collect(c);
   if (int rc = peer_check(c)) return rc;
+  if (fl[6]) {   // the loss assembly inside a sweep gave up waiting for a partial (PassFin): never seen; not survivable silently
+    if (int rc = fill_ll_empty(c)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return fail(NBMF_ERR_STATE, "internal: a sweep's loss assembly timed out waiting for its workgroups' partials");
+  }
   const int nit = fl[1];
   if (nit < 1 || nit > max_iter) return fail(NBMF_ERR_STATE, "internal: device reported n_iter=%d", nit);
   if (int rc = report(nit)) return rc;

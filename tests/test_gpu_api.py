@@ -676,3 +676,30 @@ def test_measured_mfma_peak_is_near_the_datasheet(hip):
     assert 74.0 <= p["tflops"] <= 80.0, p
     a, b, c = hip.engine_stats()
     assert a >= 0 and b >= 0 and c >= 0
+
+
+def test_loss_assembly_inside_the_sweep_gives_up_loudly_not_silently(hip, monkeypatch):
+    """The loss of iteration t-1 is put together inside the H sweep of iteration t: every workgroup hands in its partial,
+    the sweep's last workgroup waits for all of them (nbmf_pass_kernel.inc, PassFin).  That wait is bounded.  With one
+    workgroup withholding its partial (NBMF_PASSFIN_FAULT) the run must END -- no hung grid --, come back as an error, and
+    leave the context usable: the next run, without the fault, gives the losses of a fresh context bit for bit."""
+    monkeypatch.setenv("NBMF_PERSISTENT", "0")          # the launch-per-kernel engine is the one that has this hand-off
+    r = np.random.default_rng(8)
+    Y = (r.random((600, 400)) < 0.3).astype(np.float64)
+    W = r.uniform(0.1, 0.9, (12, 600)); W /= W.sum(axis=0, keepdims=True)
+    H = r.uniform(0.1, 0.9, (12, 400))
+    with hip.Context(600, 400, 12) as ctx:
+        ctx.upload(Y)
+        ctx.set_factors(W, H)
+        good, _ = ctx.run(6, 0.0)
+        monkeypatch.setenv("NBMF_PASSFIN_FAULT", "1")
+        ctx.set_factors(W, H)
+        import time
+        t0 = time.perf_counter()
+        with pytest.raises(hip.NBMFHipError, match="timed out"):
+            ctx.run(6, 0.0)
+        assert time.perf_counter() - t0 < 5.0
+        monkeypatch.delenv("NBMF_PASSFIN_FAULT")
+        ctx.set_factors(W, H)
+        again, _ = ctx.run(6, 0.0)
+        np.testing.assert_array_equal(again, good)
