@@ -429,6 +429,19 @@ def test_bitwise_run_to_run(hip, both_small_paths):
     np.testing.assert_array_equal(a.components_, b.components_)
     np.testing.assert_array_equal(a.W_, b.W_)
     np.testing.assert_array_equal(a.loss_curve_, b.loss_curve_)
+    # ... and on the 8-byte storage paths (real-valued data; bool mask folded in / real weights), a size the launches
+    # serve with several chunks and rounds of workgroups: partial slabs and the loss slots are summed in a fixed order
+    r = np.random.default_rng(3)
+    Xr = r.random((1500, 700))
+    for mk in (r.random((1500, 700)) < 0.8, r.random((1500, 700))):
+        fits = [NBMF(n_components=48, random_state=7, max_iter=12, tol=0).fit(Xr, mask=mk) for _ in range(2)]
+        np.testing.assert_array_equal(fits[0].components_, fits[1].components_)
+        np.testing.assert_array_equal(fits[0].W_, fits[1].W_)
+        np.testing.assert_array_equal(fits[0].loss_curve_, fits[1].loss_curve_)
+        # the run of k iterations is a prefix of the run of k + 1: the last loss comes from the Theta-only sweep, the others
+        # from the next iteration's H sweep, and the two must give the same bits
+        shorter = NBMF(n_components=48, random_state=7, max_iter=11, tol=0).fit(Xr, mask=mk)
+        np.testing.assert_array_equal(shorter.loss_curve_, fits[0].loss_curve_[:11])
 
 
 def test_duchi_extension_properties(hip, both_small_paths):
