@@ -91,6 +91,59 @@ def test_full_size_iteration_properties(problem):
     assert abs(assembled - full_loss) <= 1e-12 * abs(full_loss)
 
 
+@pytest.mark.parametrize("weights", [False, True], ids=["bool-mask-folded-in", "float64-weights"])
+def test_full_size_real_valued_data(weights):
+    """configs[2]'s shape with GENUINELY real-valued V (the reference accepts any V in [0, 1], _base.py:90; its tests feed
+    np.random.rand) -- the general path of the sweeps at full size: 8 bytes per entry with the bool mask folded in, 16 with
+    float64 weights (half the rows: 2 x 4.3 GB of tiles per image).  Slice-exact H and W updates (<= 1e-12), the loss of
+    the start against the oracle on the WHOLE matrix (1e-10: what the Theta-only sweep sums), monotone, bitwise repeat, and
+    a k-iteration run as a prefix of a (k+1)-iteration one."""
+    from nbmf_mm_amd import _hip
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import init_factors
+    Mr = M // 2 if weights else M
+    r = np.random.default_rng(77)
+    X = r.random((Mr, N))
+    Mk = r.random((Mr, N)) if weights else (r.random((Mr, N)) < 0.9)
+    W0, H0 = init_factors(Mr, N, K, seed=1)
+    Mf = Mk if weights else Mk.astype(np.float64)
+    with _hip.Context(Mr, N, K) as ctx:
+        ctx.set_hyper(ALPHA, BETA, EPS)
+        assert ctx.upload(X, mask=Mk) is False
+        ctx.set_factors(W0, H0)
+        want = orc.mm_loss(X, W0, H0, Mf, ALPHA, BETA, EPS)
+        loss0 = ctx.loss()
+        assert abs(loss0 - want) <= 1e-10 * abs(want)
+        l1, _ = ctx.run(1, 0.0)
+        W1, H1 = ctx.get_factors()
+        cols = np.random.default_rng(1).choice(N, 160, replace=False)
+        rows = np.random.default_rng(2).choice(Mr, 320, replace=False)
+        Ym = X[:, cols] * Mf[:, cols]
+        theta = W0.T @ H0[:, cols]
+        num = H0[:, cols] * (W0 @ (Ym / (theta + EPS))) + (ALPHA - 1)
+        den = (1 - H0[:, cols]) * (W0 @ ((1 - Ym) / (1 - theta + EPS))) + (BETA - 1)
+        np.testing.assert_allclose(H1[:, cols], np.clip(num / (num + den + EPS), EPS, 1 - EPS), rtol=0, atol=1e-12)
+        Yr, Mrr = X[rows], Mf[rows]
+        th_t = H1.T @ W0[:, rows]
+        Wn = W0[:, rows] * (H1 @ ((Yr.T * Mrr.T) / (th_t + EPS)) + (1 - H1) @ (((1 - Yr).T * Mrr.T) / (1 - th_t + EPS)))
+        Wn = Wn / N
+        np.testing.assert_allclose(W1[:, rows], Wn / Wn.sum(axis=0, keepdims=True), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(W1.sum(axis=0), 1.0, atol=1e-12)
+        assert H1.min() >= EPS and H1.max() <= 1 - EPS
+        more, _ = ctx.run(4, 0.0)
+        curve = np.concatenate([[loss0], l1, more])
+        assert all(curve[i] <= curve[i - 1] + 1e-12 for i in range(1, len(curve)))
+        Wa, Ha = ctx.get_factors()
+        ctx.set_factors(W1, H1)
+        again, _ = ctx.run(4, 0.0)
+        np.testing.assert_array_equal(more, again)
+        np.testing.assert_array_equal(Ha, ctx.get_factors()[1])
+        ctx.set_factors(W1, H1)
+        three, _ = ctx.run(3, 0.0)
+        np.testing.assert_array_equal(three, more[:3])
+
+
 def test_tall_narrow_and_wide_short_shapes():
     """Index ranges at the extremes: 1.2 M x 24 (more pack tile-rows than one launch's grid.y holds)
     and its transpose through dir-beta; both against each other (the transpose identity is bitwise)
