@@ -107,6 +107,9 @@
 #ifndef NBMF_GEN_H_WGS
 #define NBMF_GEN_H_WGS 2   // general path, H sweep at K <= 64: workgroups per CU the kernel is compiled for (3 needs <= 168 registers)
 #endif
+#ifndef NBMF_LOG_REPLICATED
+#define NBMF_LOG_REPLICATED 0   // 1 = experiment (measurement builds of the DATA_F64 sweeps at K <= 64 only): the logarithm's table as 128 entries x 16 copies, conflict-free gathers, series to r^6/6
+#endif
 #ifndef NBMF_FAIR_PRIO
 #define NBMF_FAIR_PRIO 0   // 1 = experiment: issue priorities of the workgroups that share a CU rotate trip by trip (pass_kernel)
 #endif
