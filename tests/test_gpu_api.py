@@ -117,9 +117,25 @@ def test_large_input_range_check_happens_on_the_device():
     X[4099, 4097] = 1.5
     with pytest.raises(ValueError, match="must be binary"):
         NBMF(n_components=4, max_iter=2).fit(X)
+    # NaN / inf: sklearn's check_array error, as in the reference (:83) -- for an input this big its pass over the data
+    # runs only once the device pack has found something (the pack reads every entry anyway), so a clean fit does not pay
+    # for it; the error, its wording and its precedence over "must be binary" and over a bad orientation are the same
+    for bad, word in ((np.nan, "NaN"), (np.inf, "infinity")):
+        X[4099, 4097] = bad
+        with pytest.raises(ValueError, match=word):
+            NBMF(n_components=4, max_iter=2).fit(X)
+        with pytest.raises(ValueError, match=word):
+            NBMF(n_components=4, max_iter=2, orientation="no such orientation").fit(X)
+        X[5, 5] = 1.5                                      # out of range AND not finite: sklearn's error comes first
+        with pytest.raises(ValueError, match=word):
+            NBMF(n_components=4, max_iter=2).fit(X)
+        X[5, 5] = 0.0
+    X[4099, 4097] = 0.0
+    m2 = NBMF(n_components=4, max_iter=2, tol=0, random_state=0).fit(X)
     X[4099, 4097] = np.nan
-    with pytest.raises(ValueError):                       # sklearn's check_array, as in the reference (:83)
-        NBMF(n_components=4, max_iter=2).fit(X)
+    for call in (m2.transform, m2.score):
+        with pytest.raises(ValueError, match="NaN"):
+            call(X)
 
 
 def test_sparse_input_stays_sparse_and_matches_dense():
