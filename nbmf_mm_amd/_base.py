@@ -2,6 +2,8 @@
 (src/nbmf_mm/_base.py:7-269): same constructor arguments, methods, attributes, orientation
 aliases and error messages; ``fit`` and ``transform`` run on an MI355X through libnbmf_hip.
 """
+import inspect
+
 import numpy as np
 from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array
@@ -18,8 +20,7 @@ _SPELLINGS = (
 )
 _ORIENTATION_ALIASES = dict(_SPELLINGS)
 # (the name of check_array's switch for its NaN / inf pass changed with scikit-learn 1.6)
-import inspect as _inspect
-_FINITE_KW = "ensure_all_finite" if "ensure_all_finite" in _inspect.signature(check_array).parameters else "force_all_finite"
+_FINITE_KW = "ensure_all_finite" if "ensure_all_finite" in inspect.signature(check_array).parameters else "force_all_finite"
 
 
 class NBMFMM(BaseEstimator, TransformerMixin):
