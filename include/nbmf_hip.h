@@ -75,7 +75,7 @@ int nbmf_set_hyper(nbmf_ctx* ctx, double alpha, double beta, double eps, int pro
 int nbmf_upload(nbmf_ctx* ctx, const double* x, int64_t ldx, int transposed,
                 const void* mask, int mask_kind, int64_t ldmask, int* out_flags);
 
-/* The same upload from a host array of the given element type: NBMF_DATA_F64 (nbmf_upload), or NBMF_DATA_U8 -- uint8 /
+/* The same upload from a host array of the given element type: NBMF_DATA_F64 (nbmf_upload), NBMF_DATA_F32, or NBMF_DATA_U8 -- uint8 /
  * bool data, one byte per entry, values 0 and 1 (anything else is out of range: NBMF_ERR_RANGE, the "X must be
  * binary" of _base.py:90-91).  The reference converts every input to float64 first (check_array(dtype=float64),
  * _base.py:83; `Y * mask` at _solver.py:30 would do it anyway); a caller that holds its binary matrix as bool or
@@ -84,6 +84,7 @@ int nbmf_upload(nbmf_ctx* ctx, const double* x, int64_t ldx, int transposed,
  * ldx in ELEMENTS.  The fit is bit for bit that of the float64 upload of the same values (tested). */
 #define NBMF_DATA_F64 0
 #define NBMF_DATA_U8 1
+#define NBMF_DATA_F32 2   /* float32 data: converted on the device (exactly, as the reference's dtype=float64 conversion does): 4 bytes per entry over PCIe */
 int nbmf_upload_v(nbmf_ctx* ctx, const void* x, int x_kind, int64_t ldx, int transposed,
                   const void* mask, int mask_kind, int64_t ldmask, int* out_flags);
 

@@ -80,6 +80,9 @@ class NBMFMM(BaseEstimator, TransformerMixin):
         if dt is not None and not hasattr(X, "toarray") and (dt == np.bool_ or dt == np.uint8):
             X = check_array(X, dtype=None)
             return X
+        if isinstance(X, np.ndarray) and dt == np.float32 and X.ndim == 2 and X.size > (1 << 24):
+            # a big float32 matrix likewise: four bytes per entry up to the device, which converts (exactly) and checks
+            return check_array(X, dtype=None, **{_FINITE_KW: False})
         # A big dense float array: check_array's pass over every entry for NaN / inf (0.16 s on the 4.3 GB of BASELINE
         # configs[2], a third of a 50-iteration fit) is left to the device pack, which reads every entry anyway and counts
         # the ones that are not finite or out of range; if it finds any, `_finite_or_binary_error` runs sklearn's own check
@@ -96,8 +99,8 @@ class NBMFMM(BaseEstimator, TransformerMixin):
         """The device pack refused X ("X must be binary": something outside [0, 1] or not finite).  For an input whose
         finite check was left to the device this is where sklearn's check runs: NaN / inf raise ITS error (_base.py:83),
         anything else the reference's ValueError (:90-91)."""
-        if isinstance(X, np.ndarray) and X.dtype == np.float64 and "must be binary" in str(err):
-            check_array(X, dtype=np.float64)
+        if isinstance(X, np.ndarray) and X.dtype in (np.float64, np.float32) and "must be binary" in str(err):
+            check_array(X, dtype=None)
         raise err
 
     # -- estimator API ---------------------------------------------------------------------------
@@ -123,8 +126,8 @@ class NBMFMM(BaseEstimator, TransformerMixin):
             raise
         finally:
             if not big and not sparse and X.dtype != np.bool_:
-                if X.dtype == np.float64 and X.size > (1 << 24):
-                    check_array(X, dtype=np.float64)                  # the NaN / inf pass _validated left to the device (:83 comes first)
+                if X.dtype in (np.float64, np.float32) and X.size > (1 << 24):
+                    check_array(X, dtype=None)                  # the NaN / inf pass _validated left to the device (:83 comes first)
                 if not np.all((X >= 0) & (X <= 1)):
                     raise ValueError("X must be binary") from None
         self.orientation = orientation                                # written back, :95

@@ -38,7 +38,7 @@ SYMBOLS = [
     "nbmf_set_exchange_panels", "nbmf_set_peer_timeout_ms", "nbmf_run_batch", "nbmf_batch_stats", "nbmf_sweep_info",
     "nbmf_upload_v", "nbmf_selftest_mfma_peak", "nbmf_engine_stats",
 ]
-DATA_F64, DATA_U8 = 0, 1
+DATA_F64, DATA_U8, DATA_F32 = 0, 1, 2
 
 
 #: int fn(void* user, double* buf, int64 count) -- in-place sum over ranks on a host buffer
@@ -209,10 +209,13 @@ class Context:
 
     def upload(self, x, mask=None, transposed=False):
         """x: the m x n internal matrix, or (transposed=True) the n x m user matrix whose transpose it is.
-        A bool / uint8 array goes up as it is, one byte per entry (``nbmf_upload_v``); anything else as float64."""
+        A bool / uint8 array goes up as it is, one byte per entry, a float32 array as it is, four (``nbmf_upload_v``: the
+        device converts, exactly); anything else as float64."""
         x = np.asarray(x)
         if x.dtype == np.bool_ or x.dtype == np.uint8:
             x, x_kind = np.ascontiguousarray(x).view(np.uint8), DATA_U8
+        elif x.dtype == np.float32:
+            x, x_kind = np.ascontiguousarray(x), DATA_F32
         else:
             x, x_kind = _f64c(x), DATA_F64
         want = (self.n, self.m) if transposed else (self.m, self.n)

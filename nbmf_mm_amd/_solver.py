@@ -43,9 +43,10 @@ def _binary_pattern(A):
 
 def _dense(X):
     """Dense data as the library takes it: bool / uint8 arrays as they are (one byte per entry up to the device,
-    ``nbmf_upload_v``), everything else as float64 (the reference converts every input, _base.py:83)."""
+    ``nbmf_upload_v``), float32 as it is (four; the device's conversion is the exact one ``astype(float64)`` does),
+    everything else as float64 (the reference converts every input, _base.py:83)."""
     X = np.asarray(X)
-    return X if X.dtype in (np.bool_, np.uint8) else np.asarray(X, dtype=np.float64)
+    return X if X.dtype in (np.bool_, np.uint8, np.float32) else np.asarray(X, dtype=np.float64)
 
 
 def upload_any(ctx, X, mask=None, transposed=False):

@@ -2620,8 +2620,9 @@ int nbmf_upload(nbmf_ctx* c, const double* x, int64_t ldx, int transposed, const
 int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int transposed, const void* mask, int mask_kind,
                   int64_t ldmask, int* out_flags) {
   if (!c || !xv) return fail(NBMF_ERR_ARG, "null context or data");
-  if (x_kind != NBMF_DATA_F64 && x_kind != NBMF_DATA_U8) return fail(NBMF_ERR_ARG, "x_kind must be NBMF_DATA_F64 or NBMF_DATA_U8");
-  const size_t xsz = x_kind == NBMF_DATA_U8 ? 1 : 8;   // bytes per element of the host array
+  if (x_kind != NBMF_DATA_F64 && x_kind != NBMF_DATA_U8 && x_kind != NBMF_DATA_F32)
+    return fail(NBMF_ERR_ARG, "x_kind must be NBMF_DATA_F64, NBMF_DATA_U8 or NBMF_DATA_F32");
+  const size_t xsz = x_kind == NBMF_DATA_U8 ? 1 : (x_kind == NBMF_DATA_F32 ? 4 : 8);   // bytes per element of the host array
   const double* x = (const double*)xv;
   const unsigned char* xb = (const unsigned char*)xv;
   if (mask_kind != NBMF_MASK_NONE && !mask) return fail(NBMF_ERR_ARG, "mask_kind set but mask is NULL");
@@ -2640,7 +2641,8 @@ int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int tran
     for (int64_t u = 0; u < rows && (guess_bin || guess_mask_bin); ++u) {
       const int64_t uu = (U - 1) * u / (rows > 1 ? rows - 1 : 1);
       for (int64_t v = 0; v < V && v < 4096; ++v) {
-        const double xe = x_kind == NBMF_DATA_U8 ? (double)xb[uu * ldx + v] : x[uu * ldx + v];
+        const double xe = x_kind == NBMF_DATA_U8 ? (double)xb[uu * ldx + v]
+                          : x_kind == NBMF_DATA_F32 ? (double)((const float*)xv)[uu * ldx + v] : x[uu * ldx + v];
         if (xe != 0.0 && xe != 1.0) guess_bin = false;
         if (mask_kind == NBMF_MASK_F64) {
           const double mk = ((const double*)mask)[uu * ldmask + v];

@@ -719,3 +719,30 @@ def test_loss_assembly_inside_the_sweep_gives_up_loudly_not_silently(hip, monkey
         ctx.set_factors(W, H)
         again, _ = ctx.run(6, 0.0)
         np.testing.assert_array_equal(again, good)
+
+
+def test_float32_data_goes_up_as_four_bytes_per_entry(hip):
+    """A float32 V -- real-valued or binary -- is converted to float64 by the reference before anything else
+    (check_array(dtype=float64), _base.py:83: exact).  Here a big one goes to the device as it is (nbmf_upload_v,
+    NBMF_DATA_F32) and the pack kernel converts: the same fit, bit for bit, as from the converted array; NaN and
+    out-of-range values raise what the reference raises."""
+    from nbmf_mm_amd import NBMF
+    r = np.random.default_rng(33)
+    X32 = r.random((4100, 4100)).astype(np.float32)
+    assert X32.size > (1 << 24)
+    mask = r.random(X32.shape) < 0.9
+    kw = dict(n_components=20, max_iter=4, tol=0, random_state=1)
+    a = NBMF(**kw).fit(X32.astype(np.float64), mask=mask)
+    b = NBMF(**kw).fit(X32, mask=mask)
+    np.testing.assert_array_equal(a.loss_curve_, b.loss_curve_)
+    np.testing.assert_array_equal(a.W_, b.W_)
+    np.testing.assert_array_equal(a.components_, b.components_)
+    with hip.Context(300, 200, 8) as ctx:                 # the library entry itself, any size; binary float32 data -> byte codes
+        Xb = (r.random((300, 200)) < 0.3).astype(np.float32)
+        assert ctx.upload(Xb) is True and ctx.upload(X32[:300, :200]) is False
+    X32[7, 9] = 1.25
+    with pytest.raises(ValueError, match="must be binary"):
+        NBMF(**kw).fit(X32)
+    X32[7, 9] = np.nan
+    with pytest.raises(ValueError, match="NaN"):
+        NBMF(**kw).fit(X32)
