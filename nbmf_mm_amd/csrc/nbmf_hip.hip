@@ -107,6 +107,9 @@
 #ifndef NBMF_GEN_H_WGS
 #define NBMF_GEN_H_WGS 2   // general path, H sweep at K <= 64: workgroups per CU the kernel is compiled for (3 needs <= 168 registers)
 #endif
+#ifndef NBMF_ZEPS
+#define NBMF_ZEPS 1   // binary path, plain variant: eps rides in the Theta accumulator, z = 0' / 1 + 2 eps, the H sweep's products in the form pform_inv12 describes (round 4: -8 vector instructions per H tile); 0 = round 3's |Theta - z| + eps with exact ratios
+#endif
 #ifndef NBMF_LOG_REPLICATED
 #define NBMF_LOG_REPLICATED 0   // 1 = experiment (measurement builds of the DATA_F64 sweeps at K <= 64 only): the logarithm's table as 128 entries x 16 copies, conflict-free gathers, series to r^6/6
 #endif
@@ -1252,7 +1255,18 @@ inline int wg_strips(const nbmf_ctx* c) { return WG_WAVES * pass_ns(c->KS > 1 ? 
 // un-normalised start (_base.py:175: w_free), a tiny eps -- takes the TINY variant, which keeps the reference's own
 // selects, one reciprocal per entry and a renormalisation per entry
 // (tests: test_factors_out_of_the_fits_range_follow_the_reference).
-int tiny_a(const nbmf_ctx* c) { return c->eps < 1e-70 || (NBMF_ZTRICK && !(c->eps >= 1e-12 && c->factors_in_range)); }
+//   eps < 2^-22            (NBMF_ZEPS: the high word of 1 + 2 eps is that of 1.0, so that z = 1 + 2 eps shares it).
+int tiny_a(const nbmf_ctx* c) {
+  return c->eps < 1e-70 || (NBMF_ZTRICK && !(c->eps >= 1e-12 && c->factors_in_range)) || (NBMF_ZEPS && NBMF_ZTRICK && !(c->eps < 0x1p-22));
+}
+// In what form the H sweep of the binary path's plain variant leaves its products (NBMF_ZEPS): P1' = L r (ALL entries'
+// reciprocals) and P2' = (1 + 2 eps) L R2.  The H-update kernels take 1 / (1 + 2 eps) and undo both maps on the summed
+// K x N products -- P2 = P2' / (1 + 2 eps), P1 = P1' - P2 (linear: after the sum over chunks and over ranks) --; 0 says
+// the products are P1, P2 themselves (general path, the TINY variant, sliced runs).
+double pform_inv12(const nbmf_ctx* c) {
+  if (!(NBMF_ZEPS && NBMF_ZTRICK) || c->data_kind != DATA_BIN || c->KS != 1 || tiny_a(c)) return 0.0;
+  return 1.0 / ((1.0 + c->eps) + c->eps);
+}
 
 double ll_pad_of(const nbmf_ctx* c, int strict = 0) {
   // (strictly masked sweeps count observed entries only, and a pad is never one: nothing to remove.  Until round 4 the
@@ -1494,7 +1508,7 @@ int enqueue_h_update(nbmf_ctx* c) {
                          (const double*)(c->slabH + (size_t)(c->KS + sl) * c->chunksH * per), c->chunksH, per, (long long)c->nA, 0LL,
                          0LL, (long long)c->nA, c->Hn + sl * per, c->HT + sl * per, c->HG + sl * per,
                          c->prior + 2 * (size_t)sl * blocks, ks, SLICE_K, (long long)c->n, (long long)c->nA, c->alpha - 1.0,
-                         c->beta - 1.0, c->eps, c->flags);
+                         c->beta - 1.0, c->eps, c->flags, pform_inv12(c));
       HIPCHK(hipGetLastError());
     }
     c->prior_src = c->prior;
@@ -1506,7 +1520,7 @@ int enqueue_h_update(nbmf_ctx* c) {
   hipLaunchKernelGGL(h_update_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, (const double*)c->slabH,
                      (const double*)(c->slabH + (size_t)c->chunksH * per), c->chunksH, per, (long long)c->nA, 0LL, 0LL,
                      (long long)c->nA, c->Hn, c->HT, c->HG, c->prior, c->k, c->KP, (long long)c->n, (long long)c->nA,
-                     c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags);
+                     c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags, pform_inv12(c));
   HIPCHK(hipGetLastError());
   c->prior_src = c->prior;
   c->n_prior_src = c->n_prior_blocks;
@@ -1578,7 +1592,7 @@ int enqueue_h_update_from(nbmf_ctx* c, const double* src, hipStream_t st) {
     hipLaunchKernelGGL(h_update_kernel, dim3(blocks), dim3(256), 0, st, src + sl * per, src + tot + sl * per, 1, (size_t)0,
                        (long long)c->nA, 0LL, 0LL, (long long)c->nA, c->Hn + sl * per, c->HT + sl * per, c->HG + sl * per,
                        c->prior + 2 * (size_t)sl * blocks, ks, KSK, (long long)c->n, (long long)c->nA, c->alpha - 1.0,
-                       c->beta - 1.0, c->eps, c->flags);
+                       c->beta - 1.0, c->eps, c->flags, pform_inv12(c));
     HIPCHK(hipGetLastError());
   }
   c->prior_src = c->prior;
@@ -1650,7 +1664,7 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
                        c->offHX, offPR_now, p * slots_per_panel + PEER_H_WGS * c->pv.rank, c->psl_c0[p], c->psl_wp[p],
                        (const double*)c->Hn, c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps,
                        ll_slot, c->flags, p == 0 ? fin_t : -1, offPR_prev, c->n_prior_src, c->n_obs_global, c->losses_d, tol,
-                       c->scal);
+                       c->scal, pform_inv12(c));
     HIPCHK(hipGetLastError());
     return NBMF_OK;
   };
@@ -1767,7 +1781,7 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
     const unsigned blk0 = (unsigned)((long long)c->KP * c0 / 256);
     hipLaunchKernelGGL(h_update_kernel, dim3((unsigned)((long long)c->KP * wp / 256)), dim3(256), 0, st, d1,
                        d1 + (size_t)c->KP * wp, 1, (size_t)0, wp, c0, c0, wp, c->Hn, c->HT, c->HG, c->prior + 2 * (size_t)blk0,
-                       c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags);
+                       c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags, pform_inv12(c));
     HIPCHK(hipGetLastError());
     c->prior_src = c->prior;
     c->n_prior_src = c->n_prior_blocks;
