@@ -330,7 +330,7 @@ def test_ragged_shapes_vs_oracle(hip, m, n, k, both_small_paths):
     np.testing.assert_allclose(H, Hr, rtol=0, atol=FACTOR_ATOL)
 
 
-@pytest.mark.parametrize("case", ["H_above_1", "H_exactly_1", "tiny_eps", "W_negative"])
+@pytest.mark.parametrize("case", ["H_above_1", "H_exactly_1", "tiny_eps", "W_negative", "eps_2e-7", "eps_3e-7", "eps_1e-4", "eps_1e-12"])
 def test_factors_out_of_the_fits_range_follow_the_reference(hip, case, both_small_paths):
     """The H sweep's plain variant forms its ratios from |Theta - z|, which is the reference's arithmetic while
     0 <= Theta < 1 -- what a fit keeps once it starts in range.  Starts that are NOT in range (H_init above or at 1: the
@@ -351,6 +351,10 @@ def test_factors_out_of_the_fits_range_follow_the_reference(hip, case, both_smal
         H0[r.random((k, n)) < 0.3] = 1.0
     elif case == "tiny_eps":
         kw["eps"] = 1e-30
+    elif case.startswith("eps_"):
+        # the plain variant's eps range is [1e-12, 2^-22): z = 1 + 2 eps must share its high word with 1.0.  2e-7 is
+        # inside, 3e-7 and 1e-4 outside (the select variant), 1e-12 the lower end
+        kw["eps"] = float(case[4:])
     else:
         W0[r.random((m, k)) < 0.05] *= -0.2
     with np.errstate(all="ignore"):
