@@ -268,7 +268,7 @@ def test_loss_assembled_by_the_sweeps_last_workgroup_is_the_finalize_launch_bit_
                     ctx.set_factors(W0, H0)
                     losses, n_iter = ctx.run(max_iter, tol)
                     W, H = ctx.get_factors()
-                    ctx.set_factors(W0, H0)            # (a second run on the same context: the ticket counter is back at 0)
+                    ctx.set_factors(W0, H0)            # (a second run on the same context: the loss slots are empty again)
                     again, n_again = ctx.run(max_iter, tol)
                 out[fused] = (losses, n_iter, W, H)
                 np.testing.assert_array_equal(again, losses)
