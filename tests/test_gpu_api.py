@@ -242,8 +242,9 @@ def test_progress_reports_arrive_during_the_run(monkeypatch):
 
 
 def test_loss_assembled_by_the_sweeps_last_workgroup_is_the_finalize_launch_bit_for_bit(monkeypatch):
-    """Single GPU, five-kernel path: the loss and stop test of iteration t ride in the H-pass of iteration t+1 (its
-    last workgroup to finish sums the partials in finalize_kernel's fixed order) instead of a launch of their own.
+    """Single GPU, five-kernel path: the loss and stop test of iteration t ride in the H-pass of iteration t+1 (every
+    workgroup hands its partial in with one atomic store; the sweep's last workgroup in launch order waits for all of them
+    and sums in finalize_kernel's fixed order: nbmf_pass_kernel.inc, PassFin) instead of a launch of their own.
     Same losses, same stop iteration and same factors as with the separate launch (NBMF_NO_FUSED_FINALIZE=1), for
     binary and real-valued data, with and without the stop rule, over shapes with 1 ... many workgroups per sweep."""
     from nbmf_mm_amd import _hip
