@@ -268,7 +268,7 @@ int nbmf_device_synchronize(int device);
  * caller-supplied values (op 0: Newton reciprocal used on the binary path; op 1: the natural logarithm
  * of the general path; op 2: the general path's quotient, evaluated as (1 - 0.75 x) / x; ops 3, 4: the two quotients
  * of an entry from one shared reciprocal, (1 - 0.75 x) / x and 0.75 x / ((1 - (x - 1e-8)) + 1e-8); op 5: 1/x by the
- * binary path's shared reciprocal of four, groups of four consecutive values; op 6: op 1 with the product sweeps' table) so the host can compare with IEEE 1/x,
+ * binary path's shared reciprocal of four, groups of four consecutive values; op 6: op 1 with the product sweeps' table; op 7: the table-free logarithm of the sweeps' running products) so the host can compare with IEEE 1/x,
  * log(x) and the IEEE quotients (accuracy contracts: tests/test_gpu_parity.py). */
 #define NBMF_SELFTEST_RCP 0
 #define NBMF_SELFTEST_LOG 1
@@ -279,6 +279,7 @@ int nbmf_device_synchronize(int device);
 int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y);
 
 #define NBMF_SELFTEST_LOG_1024 6  /* ... with the 1024-entry table of the product sweeps (series to r^4/4) */
+#define NBMF_SELFTEST_LOG_PRODUCT 7  /* log of a sweep's running product: no table, no memory access */
 
 /* Measurement helper with no reference counterpart: the f64 matrix rate of `device` as THIS machine delivers it -- a
  * loop of nothing but v_mfma_f64_16x16x4_f64 (four independent accumulators in VGPRs, two waves on every SIMD), one

@@ -288,6 +288,36 @@ __global__ __launch_bounds__(256) void log_table_kernel(double2* tab) {
   tab[j] = log_table_entry<10>(j);
 }
 
+// log(prod) + pexp ln 2 for the running product of a sweep's likelihood (one call per lane and sweep), without a trip to
+// memory (the library's logarithm reads tables from constant memory; in a workgroup's epilogue that is a chain of cold
+// misses).  Mantissa m in [1/sqrt 2, sqrt 2), s = (m - 1) / (m + 1), log m = 2 s (1 + s^2/3 + ... + s^18/19): |s| <= 0.172,
+// the next term is below 2^-55.  Absolute error <= 2.5e-16 + 1 ulp of the result (op 7 of nbmf_selftest_unary).  Zero,
+// NaN, infinities and negative products take the library routine: NumPy's -inf / NaN.  (Built in round 4 on the suspicion
+// that the H sweep's long epilogue -- 9 us against the W sweep's 2.7 at configs[1] -- was the library call; the finer trace
+// says 5 us of it are the workgroup's waves waiting for each other at the loss block's barrier, and the sweep's time did
+// not change.  Kept: it is deterministic, self-contained and no slower.)
+__device__ __forceinline__ double log_of_product(double prod, int pexp) {
+  const double m = __builtin_amdgcn_frexp_mant(prod);
+  if (__builtin_expect(!(m >= 0.5 && m < 1.0), 0))   // (zero: m = 0; negative: m < 0; NaN and infinity: the comparisons fail)
+    return log(prod) + (double)pexp * 0.6931471805599453094;
+  int e = __builtin_amdgcn_frexp_exp(prod) + pexp;
+  const bool low = m < 0.70710678118654752440;
+  const double m2 = low ? m + m : m;
+  e -= low ? 1 : 0;
+  const double s = (m2 - 1.0) * rcp_nr(m2 + 1.0);
+  const double w = s * s;
+  double p = __builtin_fma(w, 1.0 / 19.0, 1.0 / 17.0);
+  p = __builtin_fma(w, p, 1.0 / 15.0);
+  p = __builtin_fma(w, p, 1.0 / 13.0);
+  p = __builtin_fma(w, p, 1.0 / 11.0);
+  p = __builtin_fma(w, p, 1.0 / 9.0);
+  p = __builtin_fma(w, p, 1.0 / 7.0);
+  p = __builtin_fma(w, p, 0.2);
+  p = __builtin_fma(w, p, 0.33333333333333331483);
+  p = __builtin_fma(w, p, 1.0);
+  return __builtin_fma(s + s, p, (double)e * 0.69314718055994530942);
+}
+
 // Per-lane selects on a 64-bit wave mask, written out because the pass kernels are VALU-issue bound next to
 // their MFMAs: a byte test is ONE SDWA compare (hipcc otherwise emits v_and + v_cmp), a double select is two
 // v_cndmask_b32 (with the zero / negated alternative folded into the operand).
@@ -920,22 +950,22 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
     // spread of the entries and exits, mean prologue / loop / epilogue.  Serialises the stream (one launch at a time).
     const size_t n_wg = (size_t)grid.x * grid.y;
     unsigned long long* tr = nullptr;
-    hipError_t e = dmalloc(&tr, sizeof(unsigned long long) * 5 * n_wg);
+    hipError_t e = dmalloc(&tr, sizeof(unsigned long long) * 8 * n_wg);
     if (e != hipSuccess) return e;
     a.trace = tr;
     hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_ask, st, a);
-    std::vector<unsigned long long> h(5 * n_wg);
+    std::vector<unsigned long long> h(8 * n_wg);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipMemcpy(h.data(), tr, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
     dfree(tr);
     if (e != hipSuccess) return e;
     unsigned long long t_first = ~0ull, t_last = 0, last_entry = 0, first_exit = ~0ull;
-    double pro = 0, loop = 0, epi = 0;
+    double pro = 0, loop = 0, epi = 0, epi_loss = 0, epi_slab = 0;
     std::vector<double> exits;
     size_t live = 0;
     for (size_t i = 0; i < n_wg; ++i) {
-      const unsigned long long* t = h.data() + 5 * i;
+      const unsigned long long* t = h.data() + 8 * i;
       if (!t[3]) continue;
       ++live;
       t_first = std::min(t_first, t[0]);
@@ -945,6 +975,8 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
       pro += (double)(t[1] - t[0]);
       loop += (double)(t[2] - t[1]);
       epi += (double)(t[3] - t[2]);
+      epi_loss += (double)(t[5] - t[2]);
+      epi_slab += (double)(t[6] - t[5]);
       exits.push_back((double)t[3]);
     }
     if (live) {
@@ -953,7 +985,7 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
       double dur[16] = {0};
       int cnt[16] = {0};
       for (size_t i = 0; i < n_wg; ++i) {
-        const unsigned long long* t = h.data() + 5 * i;
+        const unsigned long long* t = h.data() + 8 * i;
         if (!t[3]) continue;
         dur[t[4] & 15] += (double)(t[3] - t[0]);
         ++cnt[t[4] & 15];
@@ -965,9 +997,10 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
       std::sort(exits.begin(), exits.end());
       const double us = 0.01;   // 100 MHz ticks
       fprintf(stderr, "[nbmf] pass<K=%d,data=%d,mode=%d> %zu workgroups: span %.1f us | entries spread over %.1f us | exits: first %.1f, median %.1f, "
-                      "last %.1f us before the end | per workgroup: prologue %.2f, loop %.2f, epilogue %.2f us\n", 16 * KB, DATA, MODE, live,
+                      "last %.1f us before the end | per workgroup: prologue %.2f, loop %.2f, epilogue %.2f us (loss block %.2f, slab stores %.2f)\n", 16 * KB, DATA, MODE, live,
               (double)(t_last - t_first) * us, (double)(last_entry - t_first) * us, (double)(t_last - first_exit) * us,
-              ((double)t_last - exits[exits.size() / 2]) * us, 0.0, pro / live * us, loop / live * us, epi / live * us);
+              ((double)t_last - exits[exits.size() / 2]) * us, 0.0, pro / live * us, loop / live * us, epi / live * us, epi_loss / live * us,
+              epi_slab / live * us);
     }
     return hipSuccess;
   }
@@ -3537,7 +3570,7 @@ int nbmf_synchronize(nbmf_ctx* c) {
 }
 
 int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y) {
-  if (!x || !y || n < 1 || op < 0 || op > 6) return fail(NBMF_ERR_ARG, "bad argument");
+  if (!x || !y || n < 1 || op < 0 || op > 7) return fail(NBMF_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(device));
   const double2* ltab10 = nullptr;
   HIPCHK(log_table_device(&ltab10));

@@ -77,7 +77,7 @@ def test_shared_reciprocal_accuracy(hip):
         assert ulp.max() <= 3.0, (op, ulp.max())
 
 
-@pytest.mark.parametrize("op", [1, 6], ids=["256-entries-degree-5", "1024-entries-degree-4"])
+@pytest.mark.parametrize("op", [1, 6, 7], ids=["256-entries-degree-5", "1024-entries-degree-4", "table-free-for-the-running-product"])
 def test_log_accuracy(hip, op):
     # logarithm of the general path (table + series; the product sweeps use the 1024-entry table, whose series is a term
     # shorter, on t1 / t2 in [1e-8, 1e8]): absolute error <= 2.5e-16 + 1 ulp of the result -- the loss sums millions of
