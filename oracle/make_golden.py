@@ -4,7 +4,7 @@
 Run in the build container only:  python oracle/make_golden.py
 It imports ``nbmf_mm`` from /root/reference/src (never copied into this repo) and stores
 inputs (when not regenerable from a seed) and the reference's outputs as small fixtures.
-The case list is SURVEY.md §8c items 1-9.  The GPU box never runs this script.
+The case list is SURVEY.md §8c items 1-9, plus (item 10, round 4) storage paths and input kinds beyond them.  The GPU box never runs this script.
 """
 import os
 import sys
@@ -150,6 +150,39 @@ def main():
     _, _, l_rv, _, _ = nbmf_mm_solver(Xrv, 16, max_iter=60, tol=0, random_state=2, mask=Wts)
     np.savez_compressed(os.path.join(OUT, "midsize.npz"), unmasked=np.array(l_un), masked=np.array(l_mk),
                         dir_beta_masked=np.array(l_db), real_weighted=np.array(l_rv))
+    # 10. round-4 additions: the reference's outputs for the storage paths and input kinds the round-4 work touched --
+    #     real-valued data with real weights / with a bool mask, both orientations, FACTORS included (item 9 keeps curves
+    #     only); scipy CSR data with a CSR mask, bool data with an integer mask, float32 data (tests/test_api.py:111-123,
+    #     tests/test_public_api.py:125-134: the reference converts them all at _base.py:83); a row nobody observes (0 / 0 in
+    #     the simplex factor, NaN from then on: _solver.py:57); transform after a dir-beta fit (always the simplex-W form).
+    import scipy.sparse as sp
+    g3 = np.random.default_rng(41)
+    ex = {}
+    Xq = g3.random((90, 130))
+    Wq = g3.random((90, 130))
+    Bq = g3.random((90, 130)) < 0.8
+    for name, orient, mk in (("rw_bd", "beta-dir", Wq), ("rw_db", "dir-beta", Wq), ("rb_bd", "beta-dir", Bq), ("rb_db", "dir-beta", Bq)):
+        m10 = NBMF(n_components=7, alpha=1.3, beta=1.1, random_state=3, max_iter=25, tol=0, orientation=orient).fit(Xq, mask=mk)
+        ex[name + "_losses"], ex[name + "_W"], ex[name + "_H"] = np.array(m10.loss_curve_), m10.W_, m10.components_
+    Xb = (g3.random((70, 110)) < 0.2)
+    Mb = (g3.random((70, 110)) < 0.85)
+    base = NBMF(n_components=5, random_state=4, max_iter=20, tol=0).fit(Xb.astype(np.float64), mask=Mb.astype(np.float64))
+    ex["kinds_losses"], ex["kinds_W"], ex["kinds_H"] = np.array(base.loss_curve_), base.W_, base.components_
+    for kind, Xv, mv in (("csr", sp.csr_matrix(Xb.astype(np.float64)), sp.csr_matrix(Mb.astype(np.float64))),
+                         ("bool_int", Xb, Mb.astype(np.int32)), ("f32", Xb.astype(np.float32), Mb.astype(np.float32))):
+        mk10 = NBMF(n_components=5, random_state=4, max_iter=20, tol=0).fit(Xv, mask=mv)
+        ex["kinds_same_" + kind] = np.array(np.array_equal(mk10.loss_curve_, base.loss_curve_) and np.array_equal(mk10.W_, base.W_))
+    Mn = Mb.astype(np.float64).copy()
+    Mn[9, :] = 0.0
+    with np.errstate(all="ignore"):
+        mn = NBMF(n_components=5, random_state=4, max_iter=6, tol=0).fit(Xb.astype(np.float64), mask=Mn)
+    ex["nanrow_losses"], ex["nanrow_W"] = np.array(mn.loss_curve_), mn.W_
+    md = NBMF(n_components=5, random_state=4, max_iter=30, tol=0, orientation="dir-beta").fit(Xb.astype(np.float64))
+    np.random.seed(8)
+    ex["dirbeta_transform"] = md.transform(Xb[:12].astype(np.float64))
+    ex["dirbeta_H"] = md.components_
+    np.savez_compressed(os.path.join(OUT, "round4.npz"), **ex)
+
     print("golden fixtures written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print("  %-20s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))

@@ -566,6 +566,46 @@ def test_real_valued_data_with_a_binary_mask_every_sweep_variant(hip, k, masked)
         assert (Wr @ Hbig).max() > 1.0 and abs(ctx.loglik(clip_theta=True) / ctx.n_obs() - want) <= 1e-12 * abs(want)
 
 
+def test_round4_reference_fixtures(hip, golden, both_small_paths):
+    """The reference's own outputs (tests/golden/round4.npz, written by oracle/make_golden.py from the imported reference) for
+    real-valued data with real weights and with a bool mask under both orientations -- factors included --, for CSR / bool +
+    int / float32 inputs, for a row nobody observes, and for transform after a dir-beta fit."""
+    import scipy.sparse as sp
+    from nbmf_mm_amd import NBMF
+    g = golden("round4")
+    g3 = np.random.default_rng(41)
+    Xq, Wq = g3.random((90, 130)), g3.random((90, 130))
+    Bq = g3.random((90, 130)) < 0.8
+    Xb = (g3.random((70, 110)) < 0.2)
+    Mb = (g3.random((70, 110)) < 0.85)
+    for name, orient, mk in (("rw_bd", "beta-dir", Wq), ("rw_db", "dir-beta", Wq), ("rb_bd", "beta-dir", Bq), ("rb_db", "dir-beta", Bq)):
+        m = NBMF(n_components=7, alpha=1.3, beta=1.1, random_state=3, max_iter=25, tol=0, orientation=orient).fit(Xq, mask=mk)
+        np.testing.assert_allclose(m.loss_curve_, g[name + "_losses"], rtol=LOSS_RTOL, atol=0, err_msg=name)
+        np.testing.assert_allclose(m.W_, g[name + "_W"], rtol=0, atol=FACTOR_ATOL, err_msg=name)
+        np.testing.assert_allclose(m.components_, g[name + "_H"], rtol=0, atol=FACTOR_ATOL, err_msg=name)
+    Xf, Mf = Xb.astype(np.float64), Mb.astype(np.float64)
+    for Xv, mv in ((Xf, Mf), (sp.csr_matrix(Xf), sp.csr_matrix(Mf)), (Xb, Mb.astype(np.int32)), (Xb.astype(np.float32), Mb.astype(np.float32))):
+        m = NBMF(n_components=5, random_state=4, max_iter=20, tol=0).fit(Xv, mask=mv)
+        np.testing.assert_allclose(m.loss_curve_, g["kinds_losses"], rtol=LOSS_RTOL, atol=0)
+        np.testing.assert_allclose(m.W_, g["kinds_W"], rtol=0, atol=FACTOR_ATOL)
+        np.testing.assert_allclose(m.components_, g["kinds_H"], rtol=0, atol=FACTOR_ATOL)
+    Mn = Mf.copy()
+    Mn[9, :] = 0.0
+    m = NBMF(n_components=5, random_state=4, max_iter=6, tol=0).fit(Xf, mask=Mn)
+    assert np.isnan(m.loss_curve_).all() and np.isnan(g["nanrow_losses"]).all()      # 0 / 0 in row 9 of W, NaN from then on (:57)
+    assert np.array_equal(np.isnan(m.W_), np.isnan(g["nanrow_W"]))
+    md = NBMF(n_components=5, random_state=4, max_iter=30, tol=0, orientation="dir-beta").fit(Xf)
+    np.testing.assert_allclose(md.components_, g["dirbeta_H"], rtol=0, atol=FACTOR_ATOL)
+    md.components_ = g["dirbeta_H"]
+    np.random.seed(8)
+    Wo, keep = orc.w_only_transform(Xf[:12], g["dirbeta_H"], W0=np.random.uniform(0.1, 0.9, (12, 5)), track_positive=True)
+    np.testing.assert_array_equal(Wo, g["dirbeta_transform"])
+    np.random.seed(8)
+    got = md.transform(Xf[:12])          # always the simplex-W form, whatever the fitted orientation (_base.py:178-193)
+    assert keep.sum() >= 10              # (rows that go through negative ratios are chaotic in the reference itself)
+    np.testing.assert_allclose(got[keep], g["dirbeta_transform"][keep], rtol=0, atol=FACTOR_ATOL)
+
+
 def _vs_oracle(Y, k, mask=None, iters=15, **kw):
     from nbmf_mm_amd import nbmf_mm_solver
     W, H, l, _, n1 = nbmf_mm_solver(Y, k, max_iter=iters, tol=0, mask=mask, **kw)

@@ -183,3 +183,44 @@ def test_transform_start_is_chaotic_on_a_few_rows(golden):
         assert np.abs(Wa - Wb)[~stable].max() > 0.1
         moved.append(abs(ra.sum() - rb.sum()) / abs(ra.sum()))
     assert min(moved) > 1e-3 and max(moved) > 2.5e-3, moved
+
+
+def _round4_inputs():
+    g3 = np.random.default_rng(41)
+    Xq, Wq = g3.random((90, 130)), g3.random((90, 130))
+    Bq = g3.random((90, 130)) < 0.8
+    Xb = (g3.random((70, 110)) < 0.2)
+    Mb = (g3.random((70, 110)) < 0.85)
+    return Xq, Wq, Bq, Xb, Mb
+
+
+def test_round4_fixtures_real_valued_paths_and_input_kinds(golden):
+    """Item 10 of the fixture list (oracle/make_golden.py): what the REFERENCE gives for real-valued data with real weights
+    and with a bool mask, both orientations (factors included); that CSR / bool + int / float32 inputs give the float64
+    fit's very bits there; a row nobody observes (NaN from the first W-update on); transform after a dir-beta fit.  The
+    restatement meets all of it bitwise."""
+    g = golden("round4")
+    Xq, Wq, Bq, Xb, Mb = _round4_inputs()
+    for name, orient, mk in (("rw_bd", "beta-dir", Wq), ("rw_db", "dir-beta", Wq), ("rb_bd", "beta-dir", Bq), ("rb_db", "dir-beta", Bq)):
+        W, H, losses, _, _ = orc.solve(Xq, 7, alpha=1.3, beta=1.1, random_state=3, max_iter=25, tol=0, orientation=orient,
+                                       mask=np.asarray(mk, dtype=np.float64))
+        np.testing.assert_array_equal(np.array(losses), g[name + "_losses"])
+        np.testing.assert_array_equal(W, g[name + "_W"])
+        np.testing.assert_array_equal(H, g[name + "_H"])
+    for kind in ("csr", "bool_int", "f32"):
+        assert bool(g["kinds_same_" + kind])            # the reference converts every input to float64 first (_base.py:83)
+    Xf, Mf = Xb.astype(np.float64), Mb.astype(np.float64)
+    W, H, losses, _, _ = orc.solve(Xf, 5, random_state=4, max_iter=20, tol=0, mask=Mf)
+    np.testing.assert_array_equal(np.array(losses), g["kinds_losses"])
+    np.testing.assert_array_equal(W, g["kinds_W"])
+    Mn = Mf.copy()
+    Mn[9, :] = 0.0
+    with np.errstate(all="ignore"):
+        W, H, losses, _, _ = orc.solve(Xf, 5, random_state=4, max_iter=6, tol=0, mask=Mn)
+    np.testing.assert_array_equal(np.array(losses), g["nanrow_losses"])            # (NaN == NaN under assert_array_equal)
+    assert np.isnan(g["nanrow_losses"]).all() and np.isnan(g["nanrow_W"][9]).all()
+    np.testing.assert_array_equal(W, g["nanrow_W"])
+    Wd, Hd, _, _, _ = orc.solve(Xf, 5, random_state=4, max_iter=30, tol=0, orientation="dir-beta")
+    np.testing.assert_array_equal(Hd, g["dirbeta_H"])
+    np.random.seed(8)
+    np.testing.assert_array_equal(orc.w_only_transform(Xf[:12], Hd), g["dirbeta_transform"])
