@@ -41,104 +41,15 @@
 
 #include "../../include/nbmf_hip.h"
 
-#ifndef NBMF_K128_H_WAVES
-#define NBMF_K128_H_WAVES 2   // K=128 H-mode: waves per SIMD to compile for (2 needs the small operand groups below; 1 = 512-register form, 15 % slower)
-#endif
-#ifndef NBMF_K128_H_GROUP
-#define NBMF_K128_H_GROUP 2
-#endif
-#ifndef NBMF_GROUP
-#define NBMF_GROUP 2   // LDS operand fragments fetched per group, one group ahead of its MFMAs (8: 2.5 % slower, more VGPRs)
-#endif
-#ifndef NBMF_DUAL_THETA
-#define NBMF_DUAL_THETA 1   // two interleaved Theta accumulation chains where a wave has its SIMD to itself
-#endif
-#ifndef NBMF_STAGE_HALF
-#define NBMF_STAGE_HALF 1   // 16 KiB stages (3 workgroups per CU at K <= 64); 0 = 32 KiB stages
-#endif
-#ifndef NBMF_SADDR
-#define NBMF_SADDR 1   // stage/code loads addressed as scalar base + lane offset (see STAGE_DMA)
-#endif
-#ifndef NBMF_IEEE_DIV
-#define NBMF_IEEE_DIV 0   // general path: 1 = the compiler's IEEE division sequence instead of div_nr
-#endif
-#ifndef NBMF_XCD_MAP
-#define NBMF_XCD_MAP 1   // give each XCD whole chunks of a sweep (see pass_kernel)
-#endif
-#ifndef NBMF_R2_BY_DIFFERENCE
-#define NBMF_R2_BY_DIFFERENCE 1   // H-mode: R2 = r - R1 (one add, exact: one of the two is zero) instead of a second select (two v_cndmask): H-pass -0.5 %
-#endif
-#ifndef NBMF_BATCH_RCP
-#define NBMF_BATCH_RCP 1   // binary path: the four reciprocals of a lane's entries from one (see pass_kernel)
-#endif
-#ifndef NBMF_NT_CODES
-#define NBMF_NT_CODES 1   // the once-read code stream is loaded non-temporally: fewer factor-panel lines evicted from L2 (c3 HBM traffic per launch H 0.994 -> 0.971, W 0.910 -> 0.843, L 0.718 -> 0.640 GB; same speed)
-#endif
-#ifndef NBMF_ASM_NEGSEL
-#define NBMF_ASM_NEGSEL 1   // the W sweeps' (m ? a : -b) as two inline-assembly v_cndmask_b32 with the negation as a source modifier (see sel64_neg)
-#endif
-#ifndef NBMF_DMA_INTERLEAVE
-#define NBMF_DMA_INTERLEAVE 1   // the waves' LDS-DMA pieces interleaved (4 KiB of consecutive addresses per instant: c3 W-pass 2.15 -> 2.13 ms, H-pass 2.92 -> 2.91) instead of one contiguous run per wave (0)
-#endif
-#ifndef NBMF_SETPRIO
-#define NBMF_SETPRIO 3   // wave priorities by phase: 3 = vector phase first where it pays (see pass_kernel), 2 = everywhere, 1 = MFMA phases first, 0 = off
-#endif
-#ifndef NBMF_DIV_RESIDUAL
-#define NBMF_DIV_RESIDUAL 0   // general path: 1 = quotients with a residual correction step (div_nr)
-#endif
-#ifndef NBMF_GENERAL_BATCH4
-#define NBMF_GENERAL_BATCH4 (NBMF_BATCH_RCP && !NBMF_IEEE_DIV && !NBMF_DIV_RESIDUAL)   // general path: one reciprocal per lane and tile (see pass_kernel)
-#endif
-#ifndef NBMF_ZTRICK
-#define NBMF_ZTRICK 1   // H sweeps of the binary path: |Theta - z| and r z instead of selects (see pass_kernel)
-#endif
-#ifndef NBMF_STAGE_UNROLL
-#define NBMF_STAGE_UNROLL 2   // stages per trip of the sweep loop: with two, the LDS buffer index and the hand-over of the lane-mask registers are static
-#endif
-#ifndef NBMF_MASK_PREFETCH
-#define NBMF_MASK_PREFETCH 8   // binary sweeps: row blocks ahead of the tile in hand at which the lane-mask records are pulled into the L2 (0 = off)
-#endif
-#ifndef NBMF_RENORM_TRIP
-#define NBMF_RENORM_TRIP 1   // the likelihood's running product is renormalised once per trip of the sweep's loop instead of per tile (see pass_kernel)
-#endif
-#ifndef NBMF_GEN_PHASED
-#define NBMF_GEN_PHASED 1   // general path: a tile's four table gathers issued together, independent arithmetic while they fly
-#endif
-#ifndef NBMF_GEN_H_WGS
-#define NBMF_GEN_H_WGS 2   // general path, H sweep at K <= 64: workgroups per CU the kernel is compiled for (3 needs <= 168 registers)
-#endif
-#ifndef NBMF_ZEPS
-#define NBMF_ZEPS 1   // binary path, plain variant: eps rides in the Theta accumulator, z = 0' / 1 + 2 eps, the H sweep's products in the form pform_inv12 describes (round 4: -8 vector instructions per H tile); 0 = round 3's |Theta - z| + eps with exact ratios
-#endif
-#ifndef NBMF_LOG_REPLICATED
-#define NBMF_LOG_REPLICATED 0   // 1 = experiment (measurement builds of the DATA_F64 sweeps at K <= 64 only): the logarithm's table as 128 entries x 16 copies, conflict-free gathers, series to r^6/6
-#endif
-#ifndef NBMF_FAIR_PRIO
-#define NBMF_FAIR_PRIO 0   // 1 = experiment: issue priorities of the workgroups that share a CU rotate trip by trip (pass_kernel)
-#endif
-#ifndef NBMF_EVEN_PLACEMENT
-#define NBMF_EVEN_PLACEMENT 0   // 1 = single-round sweeps ask for as much LDS as makes every CU take the same number of workgroups (launch_pass_tt); measured in round 4: the dispatcher already places them evenly (256 workgroups in each wave slot at configs[1]), no change
-#endif
+// Build switches.  Three, all for measurement or self-test builds; every experiment that was measured and rejected
+// (two strips per wave, rotating priorities, even placement, the replicated logarithm table, register staging, IEEE /
+// residual division, inline-assembly selects, 32 KiB stages, ...) lives in docs/HISTORY.md with the commit that last
+// contained it, not here.
 #ifndef NBMF_NO_MFMA
 #define NBMF_NO_MFMA 0   // 1 = measurement build: the sweeps without their MFMAs (see NBMF_MFMA in nbmf_pass_kernel.inc)
 #endif
 #ifndef NBMF_HAZARD_SEED
 #define NBMF_HAZARD_SEED 0   // 1 = compile a kernel with a deliberate MFMA-after-inline-assembly hazard (build self-test only)
-#endif
-#ifndef NBMF_ASM_SELECT
-#define NBMF_ASM_SELECT 0   // 1 = the selects of the binary path as inline assembly (round 2; needs tools/check_asm_mfma_hazard.py)
-#endif
-#ifndef NBMF_BYTE_SET8
-#define NBMF_BYTE_SET8 1   // W sweeps: all eight byte compares of a tile in one statement (hazard distance by construction); 0 = the observed-zero compares one by one, each a step ahead of its select
-#endif
-#ifndef NBMF_TWO_STRIPS
-#define NBMF_TWO_STRIPS 0   // 1 = K <= 32, binary path: a wave sweeps two adjacent column strips (see pass_ns).  Built, parity-green (all 105 GPU tests) and measured in round 3: NO gain (configs[1] H-pass 0.216 vs 0.214 ms, W-pass 0.159 vs 0.161 ms) -- what a tile costs besides its MFMAs is the ratio arithmetic itself, not the per-wave staging
-#endif
-#ifndef NBMF_TWO_STRIPS_WGS
-#define NBMF_TWO_STRIPS_WGS 2   // ... workgroups per CU those kernels are compiled for (register budget 512 / this per lane)
-#endif
-#ifndef NBMF_LDS_DMA
-#define NBMF_LDS_DMA 1   // stage the factor panels with global_load_lds (LDS-DMA); 0 = through registers
 #endif
 
 namespace {
@@ -183,10 +94,7 @@ enum : unsigned { CB_YM = 1u, CB_ZOBS = 2u, CB_VALID = 4u };
 
 constexpr int SLICE_K = 128;      // n_components beyond this run as slices of SLICE_K components
 constexpr int PAD = 128;          // m and n are padded to multiples of 128 (8 row blocks, 8 strips)
-#ifndef NBMF_WG_WAVES
-#define NBMF_WG_WAVES 4
-#endif
-constexpr int WG_WAVES = NBMF_WG_WAVES;   // waves (= column strips) per workgroup of the pass kernel; measured: 2-wave workgroups run 30 % slower (125 vs 179 it/s at c3)
+constexpr int WG_WAVES = 4;   // waves (= column strips) per workgroup of the pass kernel; measured: 2-wave workgroups run 30 % slower (125 vs 179 it/s at c3)
 constexpr size_t PASS_SLACK = 65536;   // bytes allocated behind every image the sweeps stream: their prefetch runs one stage (<= 32 KiB) past the last block
 constexpr int STAGE_BYTES = 32768; // one LDS stage: NB row blocks x (T + G operand images); two stages per workgroup
 
@@ -203,19 +111,6 @@ __device__ __forceinline__ double rcp_nr(double d) {
   const double e = __builtin_fma(-d, r, 1.0);
   const double p = __builtin_fma(e, e, e);
   return __builtin_fma(r, p, r);
-}
-
-// Quotient y / d for the general (real-valued / weighted) path: q0 = y * rcp_nr(d), then one residual
-// correction q = q0 + (y - d q0) * r (the closing step of the classic FMA division: correctly rounded whenever
-// r is the correctly rounded reciprocal, which rcp_nr delivers for all but 0.025 % of arguments, and within
-// 1 ulp otherwise).  7 VALU instructions against ~14 of the compiler's IEEE sequence (v_div_scale x2, v_rcp,
-// 5 FMAs, v_div_fmas, v_div_fixup) -- on a kernel where every VALU instruction adds to the MFMA time.
-// y == 0 gives exactly 0; d is never 0 here (Theta >= 0, so Theta + eps >= eps).
-__device__ __forceinline__ double div_nr(double y, double d) {
-  const double r = rcp_nr(d);
-  const double q0 = y * r;
-  const double rem = __builtin_fma(-d, q0, y);
-  return __builtin_fma(rem, r, q0);
 }
 
 // double from its two 32-bit halves / back (bit-level selects cost one VALU op per half)
@@ -373,49 +268,16 @@ __device__ __forceinline__ lanemask_t byte_set(uint32_t x, int byte) {   // one 
 // and being instructions hipcc knows, it inserts the wait states an MFMA reading the result needs itself.  (Round 2
 // wrote them as inline assembly: a select two instructions in front of an MFMA then went unprotected, found as
 // run-to-run differences in the single-launch kernel.)
-#if NBMF_ASM_SELECT
-__device__ __forceinline__ double sel64(lanemask_t m, double a, double b) {   // m ? a : b
-  const uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
-  const uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
-  uint32_t lo, hi;
-  __asm__("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(blo), "v"(alo), "s"(m));
-  __asm__("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(bhi), "v"(ahi), "s"(m));
-  return mk_double(lo, hi);
-}
-__device__ __forceinline__ double sel64_or0(lanemask_t m, double a) {   // m ? a : 0
-  const uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
-  uint32_t lo, hi;
-  __asm__("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"(alo), "s"(m));
-  __asm__("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(ahi), "s"(m));
-  return mk_double(lo, hi);
-}
-__device__ __forceinline__ double sel64_0or(lanemask_t m, double b) {   // m ? 0 : b
-  const uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
-  uint32_t lo, hi;
-  __asm__("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(lo) : "v"(blo), "s"(m));
-  __asm__("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(hi) : "v"(bhi), "s"(m));
-  return mk_double(lo, hi);
-}
-__device__ __forceinline__ double sel64_neg(lanemask_t m, double a, double b) {   // m ? a : -b
-  const uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
-  const uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
-  uint32_t lo, hi;
-  __asm__("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(blo), "v"(alo), "s"(m));
-  __asm__("v_cndmask_b32_e64 %0, -%1, %2, %3" : "=v"(hi) : "v"(bhi), "v"(ahi), "s"(m));   // the float negate modifier flips bit 31
-  return mk_double(lo, hi);
-}
-#else
 __device__ __forceinline__ double sel64(lanemask_t m, double a, double b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : b; }
 __device__ __forceinline__ double sel64_or0(lanemask_t m, double a) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : 0.0; }
 __device__ __forceinline__ double sel64_0or(lanemask_t m, double b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? 0.0 : b; }
-// m ? a : -b is the one select that stays inline assembly (NBMF_ASM_NEGSEL): the sign flip rides on the second
+// m ? a : -b is the one select that stays inline assembly: the sign flip rides on the second
 // v_cndmask_b32 as a source modifier, where hipcc spends a v_xor_b32 of its own (it splits the f64 select into 32-bit
 // halves only after the negation has become an instruction; written on the halves by hand, with a float negation for
 // the modifier to absorb, the select comes back as divergent BRANCHES) -- one vector instruction per entry of every W
 // sweep.  Its result is an MFMA operand, so the two wait states are the caller's business again: the pass kernel has
 // the product loop's LDS reads in between, the single-launch kernel an s_nop tied to the operand, and `make` checks
 // every build (tools/check_asm_mfma_hazard.py) and removes a library that gets it wrong.
-#if NBMF_ASM_NEGSEL
 __device__ __forceinline__ double sel64_neg(lanemask_t m, double a, double b) {
   const uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
   const uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
@@ -424,10 +286,6 @@ __device__ __forceinline__ double sel64_neg(lanemask_t m, double a, double b) {
   __asm__("v_cndmask_b32_e64 %0, -%1, %2, %3" : "=v"(hi) : "v"(bhi), "v"(ahi), "s"(m));   // the float negate modifier flips bit 31
   return mk_double(lo, hi);
 }
-#else
-__device__ __forceinline__ double sel64_neg(lanemask_t m, double a, double b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : -b; }
-#endif
-#endif
 
 __device__ __forceinline__ double wave_sum(double v) {
   // fixed butterfly order -> bitwise reproducible
@@ -869,25 +727,33 @@ void arena_release(ArenaSlot* a) {
 }
 
 // ---- the general path's logarithm table: one copy per device and process ------------------------
-const double2* g_logtab[64] = {nullptr};
+// Built when the first context of a device is created (nbmf_create, on that context's stream, which it then waits for --
+// creation synchronises anyway), never in the launch path: a first-time build there would allocate and wait for the whole
+// device under a process-wide lock -- illegal inside a stream capture, and a stall when another rank's kernel on the same
+// device is itself waiting, in-kernel, for this rank (peer transport).  Launches only read the pointer.
+std::atomic<const double2*> g_logtab[64];
 std::mutex g_logtab_mu;
+hipError_t log_table_build(int dev, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_logtab_mu);
+  if (g_logtab[dev & 63].load(std::memory_order_acquire)) return hipSuccess;
+  double2* t = nullptr;
+  hipError_t e = hipMalloc((void**)&t, 1024 * sizeof(double2));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(log_table_kernel, dim3(4), dim3(256), 0, st, t);
+  if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) {
+    hipFree(t);
+    return e;
+  }
+  g_logtab[dev & 63].store(t, std::memory_order_release);
+  return hipSuccess;
+}
+// (the launch path: a read; hipErrorNotInitialized if no context of this device was ever created)
 hipError_t log_table_device(const double2** out) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  std::lock_guard<std::mutex> lk(g_logtab_mu);
-  if (!g_logtab[dev & 63]) {
-    double2* t = nullptr;
-    if ((e = hipMalloc((void**)&t, 1024 * sizeof(double2))) != hipSuccess) return e;
-    hipLaunchKernelGGL(log_table_kernel, dim3(4), dim3(256), 0, 0, t);
-    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {   // (once per process: every stream may read it afterwards)
-      hipFree(t);
-      return e;
-    }
-    g_logtab[dev & 63] = t;
-  }
-  *out = g_logtab[dev & 63];
-  return hipSuccess;
+  *out = g_logtab[dev & 63].load(std::memory_order_acquire);
+  return *out ? hipSuccess : hipErrorNotInitialized;
 }
 
 // ---- pass launch ----------------------------------------------------------------------------
@@ -898,48 +764,13 @@ hipError_t log_table_device(const double2** out) {
 thread_local hipEvent_t tl_attach_start = nullptr, tl_attach_stop = nullptr;
 template <int KB, int DATA, int MODE, int TH, bool TINY>
 hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
-  dim3 grid(a_.Cb / (WG_WAVES * pass_ns(KB, DATA)), chunks);
+  dim3 grid(a_.Cb / WG_WAVES, chunks);
   constexpr int lds_bytes = pass_lds_bytes(KB, DATA, MODE);
   if (lds_bytes > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH, TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
   }
   PassArgs a = a_;
-  // (NBMF_EVEN_PLACEMENT, off: a sweep that fits the chip in ONE round with room to spare -- configs[1]: 1024 workgroups,
-  //  four per CU, where LDS and registers would admit five -- asks for as much LDS per workgroup as leaves room for exactly
-  //  ceil(workgroups / CUs) of them per CU.  Built on the suspicion that the dispatcher fills some CUs with five and some
-  //  with three; NBMF_PASS_TRACE showed it does not -- 256 workgroups in each of the wave slots 0..3 -- and the spread of
-  //  the workgroups' finishing times is the SIMD arbiter's: oldest wave first, slot 0 done after 168 us, slot 3 after 217.)
-  if (NBMF_FAIR_PRIO && MODE != MODE_T) {
-    static int resident = -1;   // (per instantiation)
-    if (resident < 0) {
-      int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)pass_kernel<KB, DATA, MODE, TH, TINY>, 64 * WG_WAVES, lds_bytes) != hipSuccess) n = 0;
-      resident = n;
-    }
-    int dev = 0;
-    DevInfo di;
-    if (resident > 0 && hipGetDevice(&dev) == hipSuccess && device_info(dev, &di) == hipSuccess && di.cus > 0) {
-      const long long n_wg = (long long)grid.x * grid.y;
-      const long long here = std::min<long long>(resident, (n_wg + di.cus - 1) / di.cus);
-      const char* e = getenv("NBMF_FAIR_ROUNDS");   // 1 (default): one-round sweeps only; 0: every sweep
-      const bool one_round = n_wg <= (long long)di.cus * resident;
-      if (here >= 2 && here <= 4 && (one_round || (e && atoi(e) == 0))) a.fair_mod = (int)here;
-    }
-  }
-  int lds_ask = lds_bytes;
-  if (NBMF_EVEN_PLACEMENT) {
-    int dev = 0;
-    DevInfo di;
-    if (hipGetDevice(&dev) == hipSuccess && device_info(dev, &di) == hipSuccess && di.cus > 0) {
-      const long long n_wg = (long long)grid.x * grid.y;
-      const long long per_cu = (n_wg + di.cus - 1) / di.cus;
-      if (n_wg >= di.cus && per_cu >= 2) {
-        const int even = (int)((160 * 1024 / per_cu) & ~255ll);
-        if (even > lds_ask && even <= 65536) lds_ask = even;
-      }
-    }
-  }
   if (DATA != DATA_BIN && MODE != MODE_W && MODE != MODE_T && pass_log_bits(KB) == 10) {
     hipError_t e = log_table_device(&a.ltab_g);
     if (e != hipSuccess) return e;
@@ -953,7 +784,7 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
     hipError_t e = dmalloc(&tr, sizeof(unsigned long long) * 8 * n_wg);
     if (e != hipSuccess) return e;
     a.trace = tr;
-    hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_ask, st, a);
+    hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
     std::vector<unsigned long long> h(8 * n_wg);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1007,10 +838,10 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
   if (tl_attach_start) {
     hipEvent_t e0 = tl_attach_start, e1 = tl_attach_stop;
     tl_attach_start = tl_attach_stop = nullptr;
-    hipExtLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_ask, st, e0, e1, 0, a);
+    hipExtLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, e0, e1, 0, a);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_ask, st, a);
+  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
   return hipGetLastError();
 }
 // (eps below 1e-70 on the binary path: the variant with per-entry reciprocals and renormalisation, see pass_kernel)
@@ -1263,8 +1094,8 @@ inline const void* sweep_image(const nbmf_ctx* c, int image) {
   return image == 0 ? c->dataA : c->dataB;
 }
 
-// column strips one workgroup of the pass kernels covers (4 waves x 1 or 2 strips per wave, see pass_ns)
-inline int wg_strips(const nbmf_ctx* c) { return WG_WAVES * pass_ns(c->KS > 1 ? 8 : c->KB, c->data_kind); }
+// column strips one workgroup of the pass kernels covers (one per wave)
+inline int wg_strips(const nbmf_ctx*) { return WG_WAVES; }
 
 // Every sweep over image A takes in all entries of the padded mA x nA grid.  A pad entry has Theta == 0 and
 // counts as "not an observed one" (binary path: code 0; general path: y = 0, weight 0), so it contributes
@@ -1272,13 +1103,16 @@ inline int wg_strips(const nbmf_ctx* c) { return WG_WAVES * pass_ns(c->KS > 1 ? 
 // assembled (and before any all-reduce).  A strictly masked sweep skips unobserved entries, pads included --
 // except on the general path without a mask, where everything counts as observed.
 // Which variant the sweeps over image A (H-pass, evaluation sweep) take on the binary path: the plain one forms the
-// ratio block of an H sweep from |Theta - z| (pass_kernel, NBMF_ZTRICK), which IS the reference's arithmetic while
+// ratio block of an H sweep from |Theta - z| (pass_kernel), which IS the reference's arithmetic while
 // 0 <= Theta < 1 -- true throughout a fit that starts from factors in range (W on the simplex, H <= 1 - eps stay so) and
 // eps >= 1e-12 (so that 1 - eps is below 1).  Anything else -- H_init above 1, negative entries, a tiny eps -- takes the
 // TINY variant, whose selects follow `_solver.py:42-43` for any Theta.
 // Which variant of the sweeps a run takes.  The plain variant (TINY = false) forms |Theta - z| for the denominators,
 // shares one reciprocal among a lane's entries and renormalises the likelihood's product once per trip; all of that is
-// the reference's arithmetic bit for bit (binary path) or to rounding (general path) ONLY under these invariants:
+// the reference's arithmetic to rounding (one-step goldens <= 1e-13, curves <= 1e-10: tests/test_gpu_parity.py) -- since
+// round 4 no longer bit for bit on the binary path either: with eps riding in Theta's accumulator the H-update forms
+// P1 = P1' - P2' / (1 + 2 eps) from all-entry sums, so a column with no observed one gets a rounding residue (which the
+// clip to [eps, 1 - eps] absorbs) where the reference has an exact 0 -- and ONLY under these invariants:
 //   eps >= 1e-12            (1 - eps < 1 in double; sixteen factors >= eps stay above 1e-192; products of four or eight
 //                            denominators cannot underflow),
 //   W >= 0 with column sums <= 1 + 1e-12  and  0 <= H <= 1 - 1e-9   when the factors were set (factors_in_range, checked
@@ -1288,16 +1122,17 @@ inline int wg_strips(const nbmf_ctx* c) { return WG_WAVES * pass_ns(c->KS > 1 ? 
 // un-normalised start (_base.py:175: w_free), a tiny eps -- takes the TINY variant, which keeps the reference's own
 // selects, one reciprocal per entry and a renormalisation per entry
 // (tests: test_factors_out_of_the_fits_range_follow_the_reference).
-//   eps < 2^-22            (NBMF_ZEPS: the high word of 1 + 2 eps is that of 1.0, so that z = 1 + 2 eps shares it).
+//   eps < 2^-22            (binary path only: the high word of 1 + 2 eps is that of 1.0, so that z = 1 + 2 eps shares it;
+//                            the general path forms (1 + 2 eps) - t1 by plain arithmetic and has no such limit).
 int tiny_a(const nbmf_ctx* c) {
-  return c->eps < 1e-70 || (NBMF_ZTRICK && !(c->eps >= 1e-12 && c->factors_in_range)) || (NBMF_ZEPS && NBMF_ZTRICK && !(c->eps < 0x1p-22));
+  return c->eps < 1e-70 || !(c->eps >= 1e-12 && c->factors_in_range) || (c->data_kind == DATA_BIN && !(c->eps < 0x1p-22));
 }
-// In what form the H sweep of the binary path's plain variant leaves its products (NBMF_ZEPS): P1' = L r (ALL entries'
+// In what form the H sweep of the binary path's plain variant leaves its products: P1' = L r (ALL entries'
 // reciprocals) and P2' = (1 + 2 eps) L R2.  The H-update kernels take 1 / (1 + 2 eps) and undo both maps on the summed
 // K x N products -- P2 = P2' / (1 + 2 eps), P1 = P1' - P2 (linear: after the sum over chunks and over ranks) --; 0 says
 // the products are P1, P2 themselves (general path, the TINY variant, sliced runs).
 double pform_inv12(const nbmf_ctx* c) {
-  if (!(NBMF_ZEPS && NBMF_ZTRICK) || c->data_kind != DATA_BIN || c->KS != 1 || tiny_a(c)) return 0.0;
+  if (c->data_kind != DATA_BIN || c->KS != 1 || tiny_a(c)) return 0.0;
   return 1.0 / ((1.0 + c->eps) + c->eps);
 }
 
@@ -1609,7 +1444,7 @@ int enqueue_reduce_h_all(nbmf_ctx* c, double* dst, hipStream_t st) {
                        (const double*)(c->slabH + (size_t)sl * c->chunksH * per),
                        (const double*)(c->slabH + (size_t)(c->KS + sl) * c->chunksH * per), c->chunksH, (long long)per,
                        (long long)c->nA, 0LL, (long long)c->nA, (long long)c->nA, KSK, dst + sl * per, dst + tot + sl * per,
-                       (const double*)c->lossbuf, n_loss, ll_pad_of(c), sl == 0 ? dst + 2 * tot : (double*)nullptr, c->flags);
+                       (const double*)c->lossbuf, n_loss, ll_pad_of(c), sl == 0 ? dst + 2 * tot : (double*)nullptr, c->flags, pform_inv12(c));
     HIPCHK(hipGetLastError());
   }
   return NBMF_OK;
@@ -1625,7 +1460,7 @@ int enqueue_h_update_from(nbmf_ctx* c, const double* src, hipStream_t st) {
     hipLaunchKernelGGL(h_update_kernel, dim3(blocks), dim3(256), 0, st, src + sl * per, src + tot + sl * per, 1, (size_t)0,
                        (long long)c->nA, 0LL, 0LL, (long long)c->nA, c->Hn + sl * per, c->HT + sl * per, c->HG + sl * per,
                        c->prior + 2 * (size_t)sl * blocks, ks, KSK, (long long)c->n, (long long)c->nA, c->alpha - 1.0,
-                       c->beta - 1.0, c->eps, c->flags, pform_inv12(c));
+                       c->beta - 1.0, c->eps, c->flags, /*pform=*/0.0);   // (the exchanged sums are P1, P2 themselves: reduce_h_kernel)
     HIPCHK(hipGetLastError());
   }
   c->prior_src = c->prior;
@@ -1688,7 +1523,7 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
       hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)(((long long)c->KP * wp + 255) / 256)), dim3(256), 0, st,
                          (const double*)a.out1, (const double*)a.out2, c->chunksH, (long long)per, (long long)c->nA, c0, wp,
                          (long long)c->nA, c->KP, X + c0, X + per + c0, (const double*)c->lossbuf, n_loss, ll_pad_of(c),
-                         p == 0 ? X + 2 * per : (double*)nullptr, c->flags);
+                         p == 0 ? X + 2 * per : (double*)nullptr, c->flags, pform_inv12(c));
       HIPCHK(hipGetLastError());
     }
     PeerView pv = c->pv;
@@ -1697,7 +1532,7 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
                        c->offHX, offPR_now, p * slots_per_panel + PEER_H_WGS * c->pv.rank, c->psl_c0[p], c->psl_wp[p],
                        (const double*)c->Hn, c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps,
                        ll_slot, c->flags, p == 0 ? fin_t : -1, offPR_prev, c->n_prior_src, c->n_obs_global, c->losses_d, tol,
-                       c->scal, pform_inv12(c));
+                       c->scal, /*pform=*/0.0);   // (every rank's arena holds P1, P2 themselves: reduce_h_kernel)
     HIPCHK(hipGetLastError());
     return NBMF_OK;
   };
@@ -1804,7 +1639,7 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
     hipLaunchKernelGGL(reduce_h_kernel, dim3((unsigned)(((long long)c->KP * wp + 255) / 256)), dim3(256), 0, st,
                        (const double*)a.out1, (const double*)a.out2, c->chunksH, (long long)per, (long long)c->nA, c0, wp, wp,
                        c->KP, d1, d2, (const double*)c->lossbuf, n_loss, ll_pad_of(c),
-                       p == 0 ? c->Pbuf + c->ll_index : (double*)nullptr, c->flags);
+                       p == 0 ? c->Pbuf + c->ll_index : (double*)nullptr, c->flags, pform_inv12(c));
     HIPCHK(hipGetLastError());
     return all_reduce_inplace(c, d1, 2 * (size_t)c->KP * wp + (p == 0 ? 1 : 0), st);
   };
@@ -1814,7 +1649,7 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
     const unsigned blk0 = (unsigned)((long long)c->KP * c0 / 256);
     hipLaunchKernelGGL(h_update_kernel, dim3((unsigned)((long long)c->KP * wp / 256)), dim3(256), 0, st, d1,
                        d1 + (size_t)c->KP * wp, 1, (size_t)0, wp, c0, c0, wp, c->Hn, c->HT, c->HG, c->prior + 2 * (size_t)blk0,
-                       c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags, pform_inv12(c));
+                       c->k, c->KP, (long long)c->n, (long long)c->nA, c->alpha - 1.0, c->beta - 1.0, c->eps, c->flags, /*pform=*/0.0);
     HIPCHK(hipGetLastError());
     c->prior_src = c->prior;
     c->n_prior_src = c->n_prior_blocks;
@@ -2593,6 +2428,7 @@ int nbmf_create(int64_t m, int64_t n, int k, int device, nbmf_ctx** out) {
   c->KP = c->KS > 1 ? SLICE_K * c->KS : 16 * c->KB;
   if (c->KS > 1) HIPCHK(dmalloc(&c->theta, sizeof(double) * (size_t)c->mA * c->nA));
   HIPCHK(stream_acquire(device, &c->stream));
+  HIPCHK(log_table_build(device, c->stream));   // (the general path's table: once per device, never in the launch path)
 
   const size_t fw = (size_t)c->KP * c->mA * sizeof(double), fh = (size_t)c->KP * c->nA * sizeof(double);
   HIPCHK(dmalloc(&c->Wn, fw));
@@ -3573,6 +3409,7 @@ int nbmf_selftest_unary(int device, int op, int n, const double* x, double* y) {
   if (!x || !y || n < 1 || op < 0 || op > 7) return fail(NBMF_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(device));
   const double2* ltab10 = nullptr;
+  HIPCHK(log_table_build(device, nullptr));   // (a self-test entry, no context: the null stream)
   HIPCHK(log_table_device(&ltab10));
   double *d = nullptr, *o = nullptr;
   HIPCHK(dmalloc(&d, sizeof(double) * (size_t)n));
@@ -3605,6 +3442,15 @@ int nbmf_selftest_mfma_peak(int device, double target_ms, double* tflops, double
   double* out = nullptr;
   HIPCHK(dmalloc(&out, sizeof(double) * (size_t)wgs * 256));
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct Cleanup {   // (every return below, the HIPCHK ones included, frees what has been made)
+    double*& out;
+    hipEvent_t &e0, &e1;
+    ~Cleanup() {
+      if (e0) hipEventDestroy(e0);
+      if (e1) hipEventDestroy(e1);
+      if (out) dfree(out);
+    }
+  } cleanup{out, e0, e1};
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   auto timed = [&](int iters, float* ms) -> hipError_t {
@@ -3626,9 +3472,6 @@ int nbmf_selftest_mfma_peak(int device, double target_ms, double* tflops, double
     iters = (int)std::min(4.0e6, std::max(2000.0, 2000.0 * target_ms / std::max((double)ms, 1e-3)));
     e = timed(iters, &ms);
   }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  dfree(out);
   if (e != hipSuccess) return fail(NBMF_ERR_HIP, "MFMA peak self-test failed: %s", hipGetErrorString(e));
   const double mfmas_per_simd = 2.0 * 8.0 * (double)iters;                    // two waves per SIMD
   const double flop = (double)wgs * 4.0 * 8.0 * (double)iters * 2048.0;       // 16 x 16 x 4 multiply-adds per MFMA and wave

@@ -352,6 +352,24 @@ for name, data, mk in (("weights", Xr, wts), ("folded", Xr, mb), ("csr", Xs, sp.
     l1, l4 = np.array(one.loss_curve_), np.array(many.loss_curve_)
     out["paths/" + name] = dict(loss=float(np.max(np.abs(l1 - l4) / np.abs(l1))), W=float(np.abs(one.W_ - many.W_).max()),
                                 H=float(np.abs(one.components_ - many.components_).max()))
+# HETEROGENEOUS shards (round 5): the form in which a rank's H sweep leaves its products depends on that rank's own
+# shard -- byte codes or doubles, factors in range or not -- and the ranks' products are summed.  (a) real-valued V whose
+# first quarter of rows happens to be all 0 / 1: rank 0 of 4 stores byte codes (mapped products), ranks 1-3 doubles;
+# (b) binary V with ONE negative entry in W_init: the rank that holds that row leaves the plain variant, the others stay.
+Xh = g.random((900, 300))
+Xh[:225] = Xh[:225] < 0.3
+for name, data, mk, extra in (("het_storage", Xh, mb, {}),
+                              ("het_variant", (Xr < 0.3).astype(np.float64), mb, "w_init")):
+    kw = dict(n_components=24, random_state=5, max_iter=10, tol=0.0)
+    if extra == "w_init":
+        W0 = np.random.default_rng(3).uniform(0.1, 0.9, (900, 24))
+        W0[10, 3] = -0.05
+        kw.update(W_init=W0, H_init=np.random.default_rng(4).uniform(0.1, 0.9, (24, 300)))
+    one = NBMF(**kw).fit(data, mask=mk)
+    many = NBMF(n_gpus=4, devices=[0] * 4, **kw).fit(data, mask=mk)
+    l1, l4 = np.array(one.loss_curve_), np.array(many.loss_curve_)
+    out["paths/" + name] = dict(loss=float(np.max(np.abs(l1 - l4) / np.abs(l1))), W=float(np.abs(one.W_ - many.W_).max()),
+                                H=float(np.abs(one.components_ - many.components_).max()))
 try:
     NBMF(n_components=K, n_gpus=3, devices=[0, 0]).fit(X)
     out["bad_devices"] = "no error"
@@ -386,7 +404,7 @@ def test_n_gpus_behind_the_drop_in_api_eight_ranks_in_one_process():
             assert o["shapes"] == [[2100, 64], [64, 640]] and o["rng"] is True
         o = out[f"{orientation}/solver"]
         assert o["t"] == 0.0 and o["n_iter"] == 5 and o["loss"] <= 1e-12 and o["W"] <= 1e-12 and o["H"] <= 1e-12, o
-    for name in ("weights", "folded", "csr"):
+    for name in ("weights", "folded", "csr", "het_storage", "het_variant"):
         o = out["paths/" + name]
         assert o["loss"] <= 1e-12 and o["W"] <= 1e-12 and o["H"] <= 1e-12, (name, o)
     assert "devices names 2 GPUs" in out["bad_devices"]

@@ -74,6 +74,15 @@ def test_the_shipped_library_passes_and_a_seeded_violation_fails_the_build(tmp_p
     body = text[text.index("mfma_peak_kernelEPdidd:"):]
     body = body[:body.index(".Lfunc_end")]
     assert body.count("v_mfma_f64_16x16x4_f64 v[") >= 8 and "a[" not in body and "accvgpr" not in body
+    # (3) NO kernel of the library spills: every .amdhsa_kernel has a private segment of 0 bytes and no scratch_ instruction.
+    #     (Round 4 shipped pass_kernel<1, F64, L> with 144 bytes of scratch per lane -- compiled for three workgroups per CU,
+    #     168 registers -- and two small_fit_kernel variants with 36: nobody looked.  pass_wgs_per_cu() in
+    #     nbmf_pass_kernel.inc and the launch bounds of the other kernels are held to this here.)
+    priv = re.findall(r"\.amdhsa_kernel (\S+)\n(?:.*\n)*?\s*\.amdhsa_private_segment_fixed_size (\d+)", text)
+    assert len(priv) > 140
+    spilling = [(name, int(b)) for name, b in priv if int(b) != 0]
+    assert not spilling, spilling
+    assert not re.search(r"^\s*scratch_(load|store)", text, re.M)
     # the same sources with one deliberately unprotected MFMA compiled in: make must fail and leave no library behind
     out = str(tmp_path / "libseed.so")
     flags = "-O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-value -Wno-unused-result -DNBMF_HAZARD_SEED=1"

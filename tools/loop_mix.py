@@ -79,6 +79,33 @@ def main():
     tiles = n / per_tile if per_tile else 1
     for k in sorted(counts):
         print(f"  {k:10s} {counts[k]:5d}" + (f"   per tile {counts[k] / tiles:7.1f}" if per_tile else ""))
+    # The loop as runs (round 5, tools/microbench4.hip: beside f64 MFMAs a 64-bit or VOP3 vector instruction costs ~4.1
+    # cycles, v_rcp_f64 16.3, a plain 32-bit VOP2 2-3, the FIRST vector instruction behind an MFMA ~9.4 on top; scalar
+    # instructions and a lone LDS read cost nothing): MFMAs, vector runs and the issue cycles that model gives a trip.
+    seq, cyc, runs = [], 0.0, 0
+    for t in ins[a:b + 1]:
+        op = t.split()[0]
+        c = classify(op)
+        if c == "mfma":
+            k, cost = "M", 64.6
+        elif c == "valu":
+            k = "v"
+            cost = 16.3 if op.startswith(("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")) else (
+                2.5 if op in ("v_and_b32_e32", "v_or_b32_e32", "v_xor_b32_e32", "v_lshrrev_b32_e32", "v_lshlrev_b32_e32", "v_mov_b32_e32", "v_add_u32_e32", "v_sub_u32_e32") else 4.1)
+            if not seq or seq[-1][0] != "v":
+                cost += 9.4
+                runs += 1
+        else:
+            k, cost = {"lds": "L", "vmem": "G", "smem": "S", "salu": "s", "branch": "b"}.get(c, "w"), 0.0
+            if k in "sw":
+                continue   # (free beside MFMAs, and they do not break a vector run)
+        cyc += cost
+        if seq and seq[-1][0] == k:
+            seq[-1][1] += 1
+        else:
+            seq.append([k, 1])
+    print("  runs: " + " ".join(f"{k}{n}" if n > 1 else k for k, n in seq))
+    print(f"  vector runs per trip: {runs}; modelled issue cycles per trip: {cyc:.0f}" + (f" = {cyc / tiles:.0f} per tile" if per_tile else ""))
     scratch = sum(1 for t in ins if t.startswith("scratch_"))
     print(f"  scratch instructions in the whole kernel: {scratch}")
 

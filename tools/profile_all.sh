@@ -7,6 +7,8 @@
 #   c2          BASELINE configs[1]: 8192 x 8192, K=32, unmasked, normalize (stats run: 500 iterations)
 #   general     configs[2] on the 8-byte storage path (--storage f64: real-valued V semantics, bool mask)
 #   generalw    ... with float64 weight tiles (--storage f64w: 16 bytes per entry)
+#   general_k16 / general_k32   the 8-byte storage path below K = 64: 16384 x 8192, masked, K = 16 / 32
+#   c2_general  BASELINE configs[1]'s shape (8192 x 8192, K=32, unmasked, normalize) on the 8-byte storage path
 #   c5shape     BASELINE configs[4]'s shape on one GPU: internal 17000 x 360000, K=128, device-generated
 #   c4shard_peer / c4shard_rccl   BASELINE configs[3]'s per-rank shard 32768 x 8192, K=64, 1-rank communicator
 #   shard8192   the strong-scaling shard of configs[2]: 8192 x 8192, K=64, no communicator
@@ -23,6 +25,9 @@ for tag in "$@"; do
     c2) A="--M 8192 --N 8192 --K 32 --no-mask --projection normalize --steps 50 --warmup 5"; S="--M 8192 --N 8192 --K 32 --no-mask --projection normalize --steps 500 --warmup 5";;
     general) A="--storage f64 --steps 6 --warmup 2";;
     generalw) A="--storage f64w --steps 6 --warmup 2";;
+    general_k16) A="--M 16384 --K 16 --storage f64 --steps 20 --warmup 3";;
+    general_k32) A="--M 16384 --K 32 --storage f64 --steps 20 --warmup 3";;
+    c2_general) A="--M 8192 --N 8192 --K 32 --no-mask --projection normalize --storage f64 --steps 50 --warmup 5";;
     c5shape) A="--device-data --M 17000 --N 360000 --K 128 --projection normalize --steps 4 --warmup 1";;
     c4shard_peer) A="--M 32768 --force-comm --transport peer --steps 10 --warmup 3";;
     c4shard_rccl) A="--M 32768 --force-comm --transport rccl --steps 10 --warmup 3";;
