@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet fp64 matrix = 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
+PEAK_HBM_GBPS = 8000.0         # HBM3E, datasheet (MI355X_MICROARCH.md: 8.0 TB/s spec)
+ACHIEVABLE_HBM_GBPS = 6300.0   # ... of which a streaming copy reaches 6.29 TB/s (same guide): the line a kernel can be held to
 # (the MEASURED peak on the line -- roofline.peak_measured -- is taken on the device that ran the bench, after the timed
 #  region: nbmf_selftest_mfma_peak, a ~100 ms loop of nothing but v_mfma_f64_16x16x4_f64 with VGPR accumulators on all SIMDs)
 
@@ -448,6 +450,16 @@ def run_rank(args, rank, local_rank, world):
         flop_pass = 6.0 * m_loc * N * K
         achieved = flop_pass / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
         traffic, traffic_src = profiled_traffic(M, N, K, masked, world)
+        # ... and its algorithmic HBM bytes: the data image the sweep reads (1/4 byte per entry as lane-mask records, 8 as
+        # doubles, 16 with weight tiles) + one read of the streamed factor's two operand images and of the stationary one +
+        # the slab writes.  Which line binds: the larger of the two lower bounds on the
+        # launch's time, flop / 78.6 TFLOP/s and bytes / 6.3 TB/s (the achievable HBM rate).
+        bytes_per_entry = 0.25 if binary_path else (16.0 if args.storage == "f64w" else 8.0)
+        bytes_pass = m_loc * N * bytes_per_entry + 2.0 * h_chunks * K * N * 8 + 2.0 * m_loc * K * 8 + N * K * 8.0
+        t_mfma = flop_pass / (PEAK_FP64_MFMA_TFLOPS * 1e12)
+        t_hbm = bytes_pass / (ACHIEVABLE_HBM_GBPS * 1e9)
+        bound = "hbm" if t_hbm > t_mfma else "mfma"
+        hbm_gbps = bytes_pass / (h_ms * 1e-3) / 1e9 if h_ms > 0 else 0.0
         if f64 and f64.get("hpass_tflops"):
             f64["frac_of_measured"] = f64["hpass_tflops"] / peak_meas["tflops"]
         by_proj = {args.projection: its, other: args.steps / dt_other}
@@ -473,9 +485,20 @@ def run_rank(args, rank, local_rank, world):
                                                              if transport.startswith("peer") else "all-reduce of 2*K*N+1 doubles"
                                                              + (" in two overlapped panels" if transport.endswith("2") else ""))
                                     + " per iteration)") if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
-                         "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+            "roofline": {"bound": bound, "kernel": "pass_kernel<MODE_H> (fused Theta + ratios + 2 back-products + loglik)",
+                         "achieved": achieved if bound == "mfma" else hbm_gbps,
+                         "peak": PEAK_FP64_MFMA_TFLOPS if bound == "mfma" else PEAK_HBM_GBPS,
+                         "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS if bound == "mfma" else hbm_gbps / PEAK_HBM_GBPS,
+                         # both lines, whichever binds: the fraction of the f64 MFMA peak, and of the HBM rate (datasheet
+                         # 8 TB/s and the 6.3 TB/s a streaming copy achieves); `binding_frac` = the launch's lower bound
+                         # (the larger of flop / 78.6 T and bytes / 6.3 T) over its measured time
+                         "mfma": {"achieved_tflops": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+                                  "algorithmic_flop_per_launch": flop_pass},
+                         "hbm": {"achieved_gbps": hbm_gbps, "peak": PEAK_HBM_GBPS, "frac": hbm_gbps / PEAK_HBM_GBPS,
+                                 "achievable": ACHIEVABLE_HBM_GBPS, "frac_of_achievable": hbm_gbps / ACHIEVABLE_HBM_GBPS,
+                                 "algorithmic_bytes_per_launch": bytes_pass},
+                         "binding_frac": (max(t_mfma, t_hbm) / (h_ms * 1e-3)) if h_ms > 0 else None,
                          "peak_measured": peak_meas["tflops"], "frac_of_measured": achieved / peak_meas["tflops"],
                          "peak_measured_how": "nbmf_selftest_mfma_peak on this device after the timed region: %.1f ms of bare "
                                               "v_mfma_f64_16x16x4_f64 (VGPR accumulators, two waves per SIMD): %.2f cycles per MFMA "
@@ -485,8 +508,7 @@ def run_rank(args, rank, local_rank, world):
                                          "reads -- lane-mask records, m*N/4 bytes, on the binary path -- + 2*chunks*K*N*8 slab bytes + one "
                                          "read of the streamed factor's two operand images (2*m*K*8) and of the stationary one (N*K*8) = "
                                          "%.3g; what a launch reads beyond that is those images again, once per XCD round of a chunk's "
-                                         "workgroups: DESIGN.md 4.1, 5)" % (m_loc * N * (0.25 if binary_path else (16 if args.storage == "f64w" else 8))
-                                                                        + 2.0 * h_chunks * K * N * 8 + 2.0 * m_loc * K * 8 + N * K * 8.0),
+                                         "workgroups: DESIGN.md 4.1, 5)" % bytes_pass,
                          "hpass_ms": h_ms, "wpass_ms": w_ms, "timed_launches": int(tim["hpass_launches"]), "event_stride": event_stride,
                          # the whole iteration against the same peak, two ways: EXECUTED MFMA flop (the W-pass runs one
                          # back-product instead of two, SURVEY N4: 6 + 4 = 10*m*N*K) -- the utilisation figure -- and the
@@ -515,6 +537,17 @@ def run_rank(args, rank, local_rank, world):
             out["parity"] = {"rel_nll_vs_oracle": abs(hloss - closs) / abs(closs), "hip_nll": hloss, "oracle_nll": closs,
                              "sample": f"first {sample_rows} rows, same init, {1 + cpu_iters} iterations, projection={args.projection}",
                              "tolerance": 1e-8}
+            # ... and on the PINNED path: projection="normalize" is the reference's own code (_solver.py:54,57), the oracle
+            # path held bitwise to the reference's golden files (duchi is the README-only extension: parity unpinned)
+            if args.projection != "normalize":
+                _, _, closs_n = cpu_baseline(N, K, args.seed, masked, "normalize", sample_rows, cpu_iters)
+                hloss_n = hip_sample_loss(N, K, args.seed, masked, "normalize", dev_index, sample_rows, cpu_iters)
+                out["parity_normalize"] = {"rel_nll_vs_oracle": abs(hloss_n - closs_n) / abs(closs_n), "hip_nll": hloss_n,
+                                           "oracle_nll": closs_n, "pinned": "oracle bitwise equal to the reference on tests/golden/*.npz",
+                                           "sample": f"first {sample_rows} rows, same init, {1 + cpu_iters} iterations, projection=normalize",
+                                           "tolerance": 1e-8}
+            else:
+                out["parity_normalize"] = dict(out["parity"], pinned="oracle bitwise equal to the reference on tests/golden/*.npz")
         print(json.dumps(out), flush=True)
     group.close()
 

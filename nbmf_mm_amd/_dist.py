@@ -217,7 +217,7 @@ def fit_row_sharded(Y_local, M_global, r0, n_components, group, max_iter=500, to
 
 def fit_sharded(V_local, global_shape, offset, n_components, group, orientation="beta-dir", shard="rows",
                 max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None, H_init=None, mask_local=None,
-                random_state=None, eps=1e-8, projection="normalize", device=0, transport="auto"):
+                random_state=None, eps=1e-8, projection="normalize", device=0, transport="auto", progress=None):
     """Sharded fit in the user's orientation, V split over the ranks by ``shard`` = "rows"
     (``V_local = V[offset:offset+len, :]``) or "cols" (``V_local = V[:, offset:offset+len]``).
 
@@ -227,6 +227,8 @@ def fit_sharded(V_local, global_shape, offset, n_components, group, orientation=
     The factor indexed by the split axis comes back as this rank's slice, the other one whole:
     returns ``(W, H, losses, n_iter)`` with W (rows_here, k) and H (k, cols_here).
     Custom inits are GLOBAL arrays; under dir-beta they are swapped only if BOTH are given (:122-123).
+    ``progress(first, losses)``: called from inside the run with every ten finished iterations' losses (the reference
+    prints inside its loop, :165-166); the losses are the same on every rank, so one rank's callback is enough.
     """
     from ._solver import _dense, _projection_code, upload_any
     if not hasattr(V_local, "toarray"):
@@ -256,6 +258,8 @@ def fit_sharded(V_local, global_shape, offset, n_components, group, orientation=
         upload_any(ctx, V_local, mask_local, transposed=transposed)    # the pack applies the transpose
         ctx.set_factors(np.ascontiguousarray(W0), np.ascontiguousarray(H0))
         attach_comm(ctx, group, transport, shard_axis=axis)
+        if progress is not None:
+            ctx.set_progress(progress, every=10)
         losses, n_iter = ctx.run(int(max_iter), float(tol))
         Wk, Hk = ctx.get_factors()
     W_out, H_out = (Hk.T, Wk) if transposed else (Wk.T, Hk)           # un-transpose, _solver.py:178-184
@@ -294,10 +298,11 @@ def fit_in_process(V, n_components, n_gpus, devices=None, orientation="beta-dir"
         n_dev = _hip.device_count()
         if any(d < 0 or d >= n_dev for d in devices):
             raise ValueError(f"devices {devices} but {n_dev} GPUs are visible")
-        if len(set(devices)) < n_gpus and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 2 * n_gpus:
+        if len(set(devices)) < n_gpus and _hip.hw_queues_at_load() < 2 * n_gpus:
             raise ValueError(f"{n_gpus} ranks on {len(set(devices))} device(s): ranks that share a GPU wait for each other inside "
                              f"kernels, so their streams need hardware queues of their own -- start the process with "
-                             f"GPU_MAX_HW_QUEUES={2 * n_gpus} or more")
+                             f"GPU_MAX_HW_QUEUES={2 * n_gpus} or more (it is read when the HIP runtime starts: "
+                             f"{_hip.hw_queues_at_load()} then; setting it now changes nothing)")
     if not hasattr(V, "toarray"):
         from ._solver import _dense
         V = _dense(V)
@@ -326,18 +331,27 @@ def fit_in_process(V, n_components, n_gpus, devices=None, orientation="beta-dir"
     groups = _rendezvous.LocalGroup.make(n_gpus)
     results, errors = [None] * n_gpus, [None] * n_gpus
 
+    def _report(first, values):
+        # the reference prints inside its loop (:165-166): rank 0's context reports the (summed, hence global) losses every
+        # ten iterations WHILE the ranks run, as the single-GPU solver does (nbmf_set_progress)
+        for it, loss in enumerate(values, start=first):
+            if it % 10 == 0:
+                print(f"Iter {it:4d}: Loss = {loss:.6f}", flush=True)
+
     def body(r):
         r0, r1 = shard_bounds(M, n_gpus, r)
+        live = {"progress": _report} if (verbose > 0 and r == 0) else {}
         try:
             with groups[r] as g:
                 results[r] = rank_fit(V[r0:r1], (M, N), r0, K, g, orientation=orientation, shard="rows", max_iter=max_iter,
                                       tol=tol, alpha=alpha, beta=beta, W_init=W_user, H_init=H_user,
                                       mask_local=None if mask is None else mask[r0:r1], random_state=None, eps=eps,
-                                      projection=projection, device=devices[r], transport=transport)
+                                      projection=projection, device=devices[r], transport=transport, **live)
         except BaseException as e:                                       # noqa: B902 (re-raised in the caller's thread)
             errors[r] = e
 
-    threads = [threading.Thread(target=body, args=(r,), name=f"nbmf-rank-{r}") for r in range(n_gpus)]
+    # (daemon threads: a Ctrl-C in the caller's join() must be able to end the process even while a rank sits in a HIP call)
+    threads = [threading.Thread(target=body, args=(r,), name=f"nbmf-rank-{r}", daemon=True) for r in range(n_gpus)]
     for t in threads:
         t.start()
     for t in threads:
@@ -352,12 +366,9 @@ def fit_in_process(V, n_components, n_gpus, devices=None, orientation="beta-dir"
     H = results[0][1]
     W, H = _touch_up(W, H, orientation)
     losses = [float(v) for v in losses]
-    if verbose > 0:
-        for it, loss in enumerate(losses):
-            if it % 10 == 0:
-                print(f"Iter {it:4d}: Loss = {loss:.6f}", flush=True)   # :165-166 (after the run: the ranks run unobserved)
-        if n_iter < int(max_iter):
-            print(f"Converged at iteration {n_iter - 1}")                # :172-173
+    if verbose > 0 and (n_iter < int(max_iter) or (n_iter > 1 and losses[-2] != 0 and
+                                                   abs(losses[-2] - losses[-1]) / abs(losses[-2]) < tol)):
+        print(f"Converged at iteration {n_iter - 1}")                    # :172-173 (the same rule as the single-GPU solver)
     return W, H, losses, 0.0, n_iter
 
 

@@ -83,6 +83,19 @@ def _autobuild(path):
             raise NBMFHipError(f"building {path} failed:\n{r.stdout[-2000:]}")
 
 
+_HW_QUEUES_AT_LOAD = None
+
+
+def hw_queues_at_load():
+    """GPU_MAX_HW_QUEUES as it stood when the library (and with it, at the latest, the HIP runtime) was loaded; the
+    runtime's default (4) if it was not set."""
+    load()
+    try:
+        return int(_HW_QUEUES_AT_LOAD) if _HW_QUEUES_AT_LOAD is not None else 4
+    except ValueError:
+        return 4
+
+
 def load():
     """Load libnbmf_hip.so (built by nbmf_mm_amd/csrc/Makefile or __graft_entry__.build())."""
     global _lib
@@ -96,6 +109,11 @@ def load():
             f"{path} not found: build it with `make -C nbmf_mm_amd/csrc` (needs hipcc); "
             "nbmf_mm_amd has no CPU fallback")
     lib = ctypes.CDLL(path)
+    # The HIP runtime reads GPU_MAX_HW_QUEUES when it starts, which is no later than the first call into this library:
+    # what the variable says NOW is what the process has (a value set afterwards changes nothing) -- _dist.fit_in_process
+    # checks this record, not the environment of the moment.
+    global _HW_QUEUES_AT_LOAD
+    _HW_QUEUES_AT_LOAD = os.environ.get("GPU_MAX_HW_QUEUES")
     if "NBMF_HIP_LIBRARY" in os.environ:
         # an explicitly named build (A/B measurements against an older library): entry points it lacks raise when called
         class _Missing:

@@ -262,7 +262,12 @@ class LocalGroup:
     """``world`` ranks that are THREADS of one process (``NBMF(n_gpus=N)``: one host thread, context and stream per GPU):
     the same small interface as :class:`Group`, over a barrier and a shared table instead of sockets.  ``make(world)``
     returns the ranks' group objects.  A rank that fails calls ``abort()`` (its ``__exit__`` does, on an exception): the
-    others' collectives then raise ``ConnectionError`` instead of waiting for it."""
+    others' collectives then raise ``ConnectionError`` instead of waiting for it.  A rank that never ARRIVES -- stuck in
+    a HIP call: a hung kernel, a collective whose partner is gone -- is given ``timeout`` seconds (default
+    ``NBMF_LOCAL_GROUP_TIMEOUT_S`` or 1800: long enough for the slowest rank's upload of a big shard, many times the
+    peer transport's own bound); then every waiting rank raises a ``ConnectionError`` that names the missing ranks."""
+
+    DEFAULT_TIMEOUT_S = 1800.0
 
     class _Shared:
         def __init__(self, world, timeout):
@@ -270,20 +275,34 @@ class LocalGroup:
             self.barrier = threading.Barrier(world)
             self.slots = [None] * world
             self.timeout = timeout
+            self.arrivals = [0] * world        # how many barrier waits each rank has entered (diagnosis of a timeout)
 
     def __init__(self, shared, rank, world):
         self._s, self.rank, self.world = shared, rank, world
 
     @classmethod
     def make(cls, world, timeout=None):
+        import os
+        if timeout is None:
+            timeout = float(os.environ.get("NBMF_LOCAL_GROUP_TIMEOUT_S", cls.DEFAULT_TIMEOUT_S))
         shared = cls._Shared(int(world), timeout)
         return [cls(shared, r, int(world)) for r in range(int(world))]
 
     def _wait(self):
         import threading
+        import time
+        s = self._s
+        s.arrivals[self.rank] += 1
+        mine, t0 = s.arrivals[self.rank], time.monotonic()
         try:
-            self._s.barrier.wait(self._s.timeout)
+            s.barrier.wait(s.timeout)
         except threading.BrokenBarrierError:
+            # broken by a failed rank's abort(), or by a timeout -- this rank's own or, once that has broken the barrier,
+            # somebody else's: whoever has not entered this wait is the one everybody was waiting for
+            missing = [r for r, n in enumerate(s.arrivals) if n < mine]
+            if missing and s.timeout is not None and time.monotonic() - t0 >= 0.9 * s.timeout:
+                raise ConnectionError(f"rank(s) {missing} of this process did not reach a collective within {s.timeout:g} s "
+                                      f"(stuck in a device call?)") from None
             raise ConnectionError("another rank of this process has failed") from None
 
     def all_gather(self, obj):

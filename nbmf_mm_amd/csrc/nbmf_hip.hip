@@ -775,7 +775,11 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
     hipError_t e = log_table_device(&a.ltab_g);
     if (e != hipSuccess) return e;
   }
-  if (getenv("NBMF_PASS_TRACE") && MODE != MODE_T) {
+  // (NBMF_PASS_TRACE=<n>: every n-th launch of each sweep kernel is traced -- with n > 1 the launches in between run back to
+  //  back, so the traced one meets the chip in the state a real run leaves it in: clocks under sustained load)
+  static const int trace_every = getenv("NBMF_PASS_TRACE") ? std::max(1, atoi(getenv("NBMF_PASS_TRACE"))) : 0;
+  static std::atomic<long> trace_count{0};   // (per instantiation)
+  if (trace_every && MODE != MODE_T && (trace_count.fetch_add(1) % trace_every) == trace_every - 1) {
     // diagnosis: where the workgroups of THIS launch spend their time outside the loop.  Every workgroup notes the wall
     // clock (100 MHz) at entry, at the top of its loop, at the loop's end and at exit; printed: the launch's span, the
     // spread of the entries and exits, mean prologue / loop / epilogue.  Serialises the stream (one launch at a time).
@@ -792,7 +796,7 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
     dfree(tr);
     if (e != hipSuccess) return e;
     unsigned long long t_first = ~0ull, t_last = 0, last_entry = 0, first_exit = ~0ull;
-    double pro = 0, loop = 0, epi = 0, epi_loss = 0, epi_slab = 0;
+    double pro = 0, loop = 0, epi = 0, epi_loss = 0, epi_slab = 0, loop_clk = 0;
     std::vector<double> exits;
     size_t live = 0;
     for (size_t i = 0; i < n_wg; ++i) {
@@ -805,6 +809,7 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
       first_exit = std::min(first_exit, t[3]);
       pro += (double)(t[1] - t[0]);
       loop += (double)(t[2] - t[1]);
+      loop_clk += (double)t[7];
       epi += (double)(t[3] - t[2]);
       epi_loss += (double)(t[5] - t[2]);
       epi_slab += (double)(t[6] - t[5]);
@@ -828,10 +833,10 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
       std::sort(exits.begin(), exits.end());
       const double us = 0.01;   // 100 MHz ticks
       fprintf(stderr, "[nbmf] pass<K=%d,data=%d,mode=%d> %zu workgroups: span %.1f us | entries spread over %.1f us | exits: first %.1f, median %.1f, "
-                      "last %.1f us before the end | per workgroup: prologue %.2f, loop %.2f, epilogue %.2f us (loss block %.2f, slab stores %.2f)\n", 16 * KB, DATA, MODE, live,
+                      "last %.1f us before the end | per workgroup: prologue %.2f, loop %.2f, epilogue %.2f us (loss block %.2f, slab stores %.2f) | shader clock in the loops %.3f GHz\n", 16 * KB, DATA, MODE, live,
               (double)(t_last - t_first) * us, (double)(last_entry - t_first) * us, (double)(t_last - first_exit) * us,
               ((double)t_last - exits[exits.size() / 2]) * us, 0.0, pro / live * us, loop / live * us, epi / live * us, epi_loss / live * us,
-              epi_slab / live * us);
+              epi_slab / live * us, loop > 0 ? loop_clk / loop * 0.1 : 0.0);
     }
     return hipSuccess;
   }
@@ -2536,6 +2541,18 @@ int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int tran
     if (!guess_mask_bin) guess_bin = false;
   }
 
+  // NBMF_UPLOAD_TRACE=1: where an upload's time goes, stage by stage (host clock, the stream drained at every mark)
+  const bool up_trace = getenv("NBMF_UPLOAD_TRACE") != nullptr;
+  auto up_t0 = std::chrono::steady_clock::now();
+  double up_copy = 0, up_pack = 0;
+  auto up_mark = [&](const char* what) {
+    if (!up_trace) return;
+    hipStreamSynchronize(c->stream);
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[nbmf upload] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - up_t0).count());
+    up_t0 = t;
+  };
+  up_mark("host sample");
   const size_t tiles = (size_t)(c->mA / 16) * (c->nA / 16);
   // staging chunk: <= 256 MiB of raw rows and <= 32768 tile rows (grid.y limit of the pack launch)
   const int64_t chunk_rows_max =
@@ -2555,6 +2572,7 @@ int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int tran
   HIPCHK(dmalloc(&raw, (size_t)chunk_rows * V * xsz));
   if (mask) HIPCHK(dmalloc(&rawm, (size_t)chunk_rows * V * msz));
 
+  up_mark("staging buffers");
   int rc = NBMF_OK;
   unsigned long long st[4] = {0, 0, 0, 0};
   // Storage paths, cheapest first: byte codes (binary data, binary or no mask); doubles with a binary (or no)
@@ -2580,6 +2598,7 @@ int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int tran
       HIPCHK(dmalloc(&c->maskB, bytes + PASS_SLACK));
     }
     HIPCHK(hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 8, c->stream));
+    up_mark("image allocations");
 
     for (int64_t u0 = 0; u0 < round_up(U, PAD); u0 += chunk_rows) {
       const int64_t urows_pad = std::min<int64_t>(chunk_rows, round_up(U, PAD) - u0);
@@ -2591,6 +2610,12 @@ int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int tran
           HIPCHK(hipMemcpy2DAsync(rawm, (size_t)V * msz, (const char*)mask + (size_t)u0 * ldmask * msz,
                                   (size_t)ldmask * msz, (size_t)V * msz, (size_t)urows, hipMemcpyHostToDevice,
                                   c->stream));
+      }
+      if (up_trace) {
+        hipStreamSynchronize(c->stream);
+        const auto t = std::chrono::steady_clock::now();
+        up_copy += std::chrono::duration<double, std::milli>(t - up_t0).count();
+        up_t0 = t;
       }
       PackArgs a{};
       a.x = raw;
@@ -2618,7 +2643,13 @@ int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int tran
       hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, c->stream, a);
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(c->stream));   // raw staging buffer is reused by the next chunk
+      if (up_trace) {
+        const auto t = std::chrono::steady_clock::now();
+        up_pack += std::chrono::duration<double, std::milli>(t - up_t0).count();
+        up_t0 = t;
+      }
     }
+    if (up_trace) fprintf(stderr, "[nbmf upload] host -> device copies %.3f ms, pack kernels %.3f ms\n", up_copy, up_pack);
     HIPCHK(hipMemcpy(st, c->stats, sizeof st, hipMemcpyDeviceToHost));
     if (st[1] != 0) {
       rc = fail(NBMF_ERR_RANGE, "X must be binary: %llu entries outside [0,1] or not finite", st[1]);
@@ -2632,13 +2663,16 @@ int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int tran
   }
   if (rc != NBMF_OK) return rc;
   if (c->data_kind < 0) return fail(NBMF_ERR_STATE, "internal: pack did not settle on a storage path");
+  up_mark("pack statistics");
   if (int rc2 = setup_workspaces(c)) return rc2;
+  up_mark("workspaces + lane masks");
   c->n_obs = (mask_kind == NBMF_MASK_NONE) ? (double)c->m * (double)c->n : (double)st[0];
   c->n_obs_global = c->n_obs;
   hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
                      c->data_kind, (long long)(c->nA / 16), (long long)c->m, (long long)c->n, c->rowcnt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
+  up_mark("row counts");
   if (out_flags) *out_flags = (c->data_kind == DATA_BIN) ? NBMF_FLAG_BINARY_PATH : 0;
   return NBMF_OK;
 }

@@ -538,7 +538,7 @@ def test_several_ranks_in_one_process_and_private_init_stream():
 
 def _oracle_rank_fit(V_local, global_shape, offset, K, group, orientation="beta-dir", shard="rows", max_iter=500, tol=1e-5,
                      alpha=1.2, beta=1.2, W_init=None, H_init=None, mask_local=None, random_state=None, eps=1e-8,
-                     projection="normalize", device=0, transport="auto"):
+                     projection="normalize", device=0, transport="auto", progress=None):
     """What ``_dist.fit_sharded`` does for ONE rank of ``fit_in_process``, with the sharded oracle in place of the GPU:
     same arguments, same return value ``(W (rows_here, k), H (k, cols_here), losses, n_iter)``."""
     from nbmf_mm_amd import _dist
@@ -558,12 +558,18 @@ def _oracle_rank_fit(V_local, global_shape, offset, K, group, orientation="beta-
 
     nobs = np.array([float(V_local.size if mk is None else np.count_nonzero(mk))])
     allreduce(nobs)
+    def reported(losses):   # (the GPU context reports every ten iterations while it runs; the oracle has only the end)
+        if progress is not None:
+            for first in range(0, len(losses), 10):
+                progress(first, losses[first:first + 10])
+        return losses
+
     if not transposed:
         Wl, H, losses = sharded_oracle.sharded_solve(V_local, mk, Wi[:, sl], Hi, alpha, beta, nobs[0], allreduce, max_iter, tol, eps)
-        return Wl.T, H, losses, len(losses)
+        return Wl.T, H, reported(losses), len(losses)
     W, Hl, losses = sharded_oracle.sharded_solve_cols(V_local.T, None if mk is None else mk.T, Wi, Hi[:, sl], alpha, beta, nobs[0],
                                                       n_int, allreduce, max_iter, tol, eps)
-    return Hl.T, W, losses, len(losses)        # un-transposed, _solver.py:178-184
+    return Hl.T, W, reported(losses), len(losses)        # un-transposed, _solver.py:178-184
 
 
 @pytest.mark.parametrize("orientation", ["beta-dir", "dir-beta"])
@@ -611,6 +617,24 @@ def test_fit_in_process_splits_seeds_and_assembles_like_the_single_fit(orientati
         _dist.fit_in_process(V, K, n_gpus, devices=[0], _rank_fit=_oracle_rank_fit)
 
 
+def test_fit_in_process_verbose_reports_through_rank_zero_only(capsys):
+    """``verbose > 0`` under ``n_gpus > 1``: the reference's lines (src/nbmf_mm/_solver.py:165-166,172-173) come from ONE
+    rank's progress callback -- every tenth iteration once, in order, with the losses of the global matrix -- and
+    "Converged at iteration" follows the single-GPU solver's rule."""
+    from nbmf_mm_amd import _dist
+    from oracle import nbmf_oracle as orc
+    g = np.random.default_rng(8)
+    V = (g.random((90, 40)) < 0.3).astype(np.float64)
+    W, H, losses, _, n_iter = _dist.fit_in_process(V, 5, 3, devices=[0] * 3, max_iter=25, tol=0, random_state=2, verbose=1,
+                                                   _rank_fit=_oracle_rank_fit)
+    out = capsys.readouterr().out.splitlines()
+    _, _, lr, _, _ = orc.solve(V, 5, max_iter=25, tol=0, random_state=2)
+    assert out == [f"Iter {it:4d}: Loss = {lr[it]:.6f}" for it in (0, 10, 20)]
+    _dist.fit_in_process(V, 5, 3, devices=[0] * 3, max_iter=400, tol=1e-3, random_state=2, verbose=1, _rank_fit=_oracle_rank_fit)
+    out = capsys.readouterr().out.splitlines()
+    assert out[-1].startswith("Converged at iteration ") and all(ln.startswith("Iter ") for ln in out[:-1])
+
+
 def test_local_group_collectives():
     import threading
     from nbmf_mm_amd import _rendezvous
@@ -630,3 +654,30 @@ def test_local_group_collectives():
     for t in ts:
         t.join(30)
     assert all(o == ([0, 10, 20, 30], "x", False, True, 1.5, [10.0, 10.0, 10.0]) for o in out)
+
+
+def test_local_group_names_the_rank_that_never_arrives():
+    """A rank stuck in a device call never reaches the next collective: the others give up after the group's timeout with
+    a ConnectionError that says which rank was missing (the default timeout is finite: NBMF_LOCAL_GROUP_TIMEOUT_S or 1800 s)."""
+    import threading
+    from nbmf_mm_amd import _rendezvous
+    assert _rendezvous.LocalGroup.make(2)[0]._s.timeout == _rendezvous.LocalGroup.DEFAULT_TIMEOUT_S
+    groups = _rendezvous.LocalGroup.make(3, timeout=0.5)
+    errs, gate = [None] * 3, threading.Event()
+
+    def body(r):
+        try:
+            groups[r].barrier()                      # everybody: fine
+            if r == 2:
+                gate.wait(10)                        # "stuck"
+                return
+            groups[r].all_gather(r)
+        except ConnectionError as e:
+            errs[r] = str(e)
+    ts = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts[:2]:
+        t.join(20)
+    gate.set()
+    assert errs[0] and errs[1] and all("rank(s) [2]" in e and "0.5 s" in e for e in errs[:2]), errs

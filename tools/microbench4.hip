@@ -99,11 +99,11 @@ __global__ __launch_bounds__(256, 2) void k_mix(double* out, int iters, double a
       acc[u & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u & 3], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int v = 0; v < NV / 8; ++v) filler<OP>(x[(u + v) & 7], y, iv[(u + v) & 7], j, lds_addr, lv[(u + v) & 7], sreg, f[(u + v) & 7], mo);
+      for (int v = 0; v < (NV >= 8 ? NV / 8 : (u < NV ? 1 : 0)); ++v) filler<OP>(x[(u + v) & 7], y, iv[(u + v) & 7], j, lds_addr, lv[(u + v) & 7], sreg, f[(u + v) & 7], mo);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (OP == OP_LDS_B128 || OP == OP_LDS_B64) __asm__ volatile("s_waitcnt lgkmcnt(0)");
-    if (MEM) __asm__ volatile("s_waitcnt vmcnt(8)");   // (keeps a run of loads in flight, as a prefetching sweep does)
+    if (MEM) __asm__ volatile("s_waitcnt vmcnt(4)");   // (keeps a run of loads in flight, as a prefetching sweep does)
   }
   __asm__ volatile("s_waitcnt vmcnt(0)");
   double s = sreg;
@@ -144,6 +144,16 @@ void run_op() {
   printf("%-22s cycles per MFMA with 0 / 1 / 4 of them per MFMA: %6.1f %6.1f %6.1f   => +%.1f for the first, +%.1f for each further one\n",
          OP_NAME[OP], cyc(t0), cyc(t8), cyc(t32), cyc(t8) - cyc(t0), (cyc(t32) - cyc(t8)) / 3.0);
   fflush(stdout);
+  if (OP == OP_GLOAD_X4 || OP == OP_GLOAD_X2 || OP == OP_LDS_DMA) {
+    // memory instructions at the density the sweeps have (one or two per 8 MFMAs: far below the bandwidth limit the rows
+    // above run into), so that what is measured is the instruction's own cost to the issuing SIMD
+    const float t1 = time_ms([&] { k_mix<OP, 1><<<g_cu * BPC, 256>>>(g_out, g_iters, 1.0, 0.5, g_stream, g_stream_bytes); });
+    const float t2 = time_ms([&] { k_mix<OP, 2><<<g_cu * BPC, 256>>>(g_out, g_iters, 1.0, 0.5, g_stream, g_stream_bytes); });
+    const float t4 = time_ms([&] { k_mix<OP, 4><<<g_cu * BPC, 256>>>(g_out, g_iters, 1.0, 0.5, g_stream, g_stream_bytes); });
+    printf("%-22s cycles per 8 MFMAs with 0 / 1 / 2 / 4 of them per 8 MFMAs: %6.1f %6.1f %6.1f %6.1f  => +%.1f, +%.1f, +%.1f each\n", OP_NAME[OP],
+           8 * cyc(t0), 8 * cyc(t1), 8 * cyc(t2), 8 * cyc(t4), 8 * (cyc(t1) - cyc(t0)), 8 * (cyc(t2) - cyc(t0)) / 2, 8 * (cyc(t4) - cyc(t0)) / 4);
+    fflush(stdout);
+  }
 }
 template <int OP>
 void run_all() {
