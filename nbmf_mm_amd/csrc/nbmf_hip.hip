@@ -2639,7 +2639,8 @@ int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int tran
       a.RbB = c->nA / 16;
       a.stats = c->stats;
       const int64_t VA = transposed ? c->mA : c->nA;
-      dim3 grid((unsigned)(VA / 16 / 4), (unsigned)(urows_pad / 16));
+      a.tile_rows = urows_pad / 16;
+      dim3 grid((unsigned)(VA / 16 / 4), (unsigned)((a.tile_rows + PACK_TILE_ROWS - 1) / PACK_TILE_ROWS));
       hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, c->stream, a);
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(c->stream));   // raw staging buffer is reused by the next chunk
