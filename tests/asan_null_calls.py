@@ -1,7 +1,10 @@
 """Run under a host-AddressSanitizer build of libnbmf_hip (tests/test_abi.py starts it with LD_PRELOAD=<asan runtime> and
 NBMF_HIP_LIBRARY=<the ASan build>): every entry point of the C ABI is called with null pointers and zero sizes -- the
 CPU-reachable part of the library: argument validation, error plumbing, the thread-local error string -- and must come
-back with an error code, not a fault.  No GPU needed (and none used: the calls fail before any device work)."""
+back with an error code, not a fault.  No GPU needed, and none used: the calls fail before any device work -- except the
+entries that take a bare DEVICE INDEX (nbmf_device_synchronize, the self-tests), which are handed device -1 here so
+that they, too, fail in argument validation on a box that has a GPU instead of initialising the runtime under the
+preloaded sanitizer."""
 import ctypes
 import os
 import sys
@@ -17,9 +20,10 @@ for name in _hip.SYMBOLS:
         continue
     fn = getattr(lib, name)
     args = []
-    for t in fn.argtypes or []:
+    bare_device = name in ("nbmf_device_synchronize", "nbmf_selftest_unary", "nbmf_selftest_mfma_peak")   # first argument: a device index
+    for i, t in enumerate(fn.argtypes or []):
         if t in (ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_longlong):
-            args.append(0)
+            args.append(-1 if (bare_device and i == 0) else 0)
         elif t is ctypes.c_double:
             args.append(0.0)
         elif t in (_hip.HOST_ALLREDUCE_FN, _hip.PROGRESS_FN):

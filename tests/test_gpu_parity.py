@@ -111,6 +111,28 @@ def test_one_step_golden_vectors(hip, golden, both_small_paths):
         assert binpath == (i < 18)          # the last vector is real-valued with a weight mask
 
 
+def test_column_without_an_observed_one_under_a_flat_prior(hip, both_small_paths):
+    """alpha = 1 (a = 0) and a column of V with no observed one: the reference's numerator H * P1 + a is an exact 0 there
+    and its update lands on the lower clip, eps.  The binary path's H sweep leaves P1 as a DIFFERENCE of all-entry sums
+    (P1' - P2' / (1 + 2 eps), round 4) -- a rounding residue of either sign instead of the exact 0 -- which the clip to
+    [eps, 1 - eps] must absorb: the same H', to 1e-13 everywhere and exactly eps in that column, masked and not."""
+    g = np.random.default_rng(12)
+    m, n, k = 96, 70, 7
+    Y = (g.random((m, n)) < 0.3).astype(np.float64)
+    Y[:, 5] = 0.0                                   # nobody has a one here
+    Y[:, 11] = 0.0
+    W = g.uniform(0.1, 0.9, (k, m))
+    W /= W.sum(axis=0, keepdims=True)
+    H = g.uniform(0.1, 0.9, (k, n))
+    for mask in (None, g.random((m, n)) < 0.8):
+        Wn, Hn, loss, binpath = _one_step(hip, Y, W, H, mask, 1.0, 1.3)
+        Wr, Hr = orc.mm_step(Y, W, H, None if mask is None else mask.astype(np.float64), 1.0, 1.3)
+        assert binpath
+        np.testing.assert_allclose(Hn, Hr, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(Wn, Wr, rtol=0, atol=1e-13)
+        assert (Hr[:, [5, 11]] == 1e-8).all() and (Hn[:, [5, 11]] == 1e-8).all()
+
+
 def test_config1_curve(hip, golden, both_small_paths):
     from nbmf_mm_amd import NBMF
     g = golden("config1")
