@@ -324,7 +324,6 @@ struct nbmf_ctx {
   bool w_free = false;             // inside nbmf_w_only_steps (the W sweeps' variant, w_pass_args)
   bool factors_in_range = false;   // W >= 0 with column sums <= 1 + 1e-12, 0 <= H <= 1 - 1e-9 when they were set: Theta stays in [0, 1) for good
   int chunksH = 0, CH_H = 0, chunksW = 0, CH_W = 0;
-  int a_ns = 1;             // column strips per wave of the sweep over image A enqueued last (pass_ns)
   int *cstartH = nullptr, *cstartW = nullptr;   // device: chunk boundaries of the two sweeps
   double *slabH = nullptr, *slabW = nullptr, *Pbuf = nullptr, *lossbuf = nullptr, *prior = nullptr, *scal = nullptr;
   double* lossfin = nullptr;   // the slots of the fused loss assembly (PassFin): LL_EMPTY in every slot between sweeps
@@ -765,7 +764,7 @@ hipError_t log_table_device(const double2** out) {
 thread_local hipEvent_t tl_attach_start = nullptr, tl_attach_stop = nullptr;
 template <int KB, int DATA, int MODE, int TH, bool TINY>
 hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
-  dim3 grid(a_.Cb / (WG_WAVES * (TH == 0 ? pass_ns(KB, DATA, MODE) : 1)), chunks);
+  dim3 grid(a_.Cb / WG_WAVES, chunks);
   constexpr int lds_bytes = pass_lds_bytes(KB, DATA, MODE);
   if (lds_bytes > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH, TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -1100,12 +1099,8 @@ inline const void* sweep_image(const nbmf_ctx* c, int image) {
   return image == 0 ? c->dataA : c->dataB;
 }
 
-// column strips one workgroup of the sweeps over image A (H and likelihood sweeps) covers: one per wave, two on the general
-// path's sweeps of real-valued data at K <= 32 (pass_ns); the W sweeps: one per wave
-inline int wg_strips_h(const nbmf_ctx* c) { return WG_WAVES * (c->KS > 1 ? 1 : pass_ns(c->KB, c->data_kind, MODE_H)); }
-inline int wg_strips_w(const nbmf_ctx*) { return WG_WAVES; }
-// ... of the sweep over image A that ran LAST (H or likelihood sweep: they may differ): what the loss partials are counted by
-inline int wg_strips(const nbmf_ctx* c) { return WG_WAVES * c->a_ns; }
+// column strips one workgroup of the pass kernels covers (one per wave)
+inline int wg_strips(const nbmf_ctx*) { return WG_WAVES; }
 
 // Every sweep over image A takes in all entries of the padded mA x nA grid.  A pad entry has Theta == 0 and
 // counts as "not an observed one" (binary path: code 0; general path: y = 0, weight 0), so it contributes
@@ -1215,7 +1210,6 @@ int enqueue_theta(nbmf_ctx* c, int image) {
 // stored, stores the total, reports the likelihood and forms its own products; then the other slices' sweeps
 // read the total.  (Theta crosses HBM 24 KS - 16 bytes per entry instead of 24 KS - 8, in one sweep fewer.)
 int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int clip) {
-  c->a_ns = 1;
   if (int rc = enqueue_theta(c, 0)) return rc;
   const size_t per = (size_t)SLICE_K * c->nA;
   const int last = c->KS - 1;
@@ -1316,7 +1310,6 @@ int enqueue_h_pass(nbmf_ctx* c, int fin_t = -1, double tol = 0.0) {
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c);
-  c->a_ns = pass_ns(c->KB, c->data_kind, MODE_H);
   if (fin_t >= 0) fin_fill(c, a, fin_t, tol, 0);
   {
     EvScope ev(c, 0, true, /*attach=*/true);
@@ -1353,7 +1346,6 @@ int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0, int fin_t = -1, d
   a.tiny_eps = tiny_a(c);
   a.strict = strict;
   a.clip = clip;
-  c->a_ns = pass_ns(c->KB, c->data_kind, MODE_L);
   if (fin_t >= 0) fin_fill(c, a, fin_t, tol, strict);
   HIPCHK(launch_pass<MODE_L>(c->KB, c->data_kind, a, c->chunksH, c->stream));
   if (int rc = enqueue_exchange_after_sweep(c, a, /*with_products=*/false, strict)) return rc;
@@ -1512,7 +1504,6 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
     if (c->KS > 1) {
       if (int rc = enqueue_a_sweeps_sliced(c, true, 0, 0)) return rc;
     } else {
-      c->a_ns = pass_ns(c->KB, c->data_kind, MODE_H);
       HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, c->stream));
     }
   }
@@ -1642,7 +1633,6 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
   a.tiny_eps = tiny_a(c);
   {
     EvScope ev(c, 0, true, /*attach=*/true);
-    c->a_ns = pass_ns(c->KB, c->data_kind, MODE_H);
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, s0));
   }
   if (two_streams) HIPCHK(hipEventRecord(c->evH, s0));
@@ -2282,9 +2272,9 @@ int setup_workspaces(nbmf_ctx* c) {
   const int NB = 8 / c->KB;
   const int slotsH = cus * resident_per_cu<MODE_H>(c->KB, c->data_kind);
   const int slotsW = cus * resident_per_cu<MODE_W>(c->KB, c->data_kind);
-  const int ns = wg_strips_h(c) / WG_WAVES;
-  pick_chunks((int)(c->nA / 16 / wg_strips_h(c)), (int)(c->mA / 16), NB, slotsH, ns, cus, /*one_round_ok=*/true, &c->chunksH, &c->CH_H);
-  pick_chunks((int)(c->mA / 16 / wg_strips_w(c)), (int)(c->nA / 16), NB, slotsW, 1, cus, /*one_round_ok=*/false, &c->chunksW, &c->CH_W);
+  const int ns = wg_strips(c) / WG_WAVES;
+  pick_chunks((int)(c->nA / 16 / wg_strips(c)), (int)(c->mA / 16), NB, slotsH, ns, cus, /*one_round_ok=*/true, &c->chunksH, &c->CH_H);
+  pick_chunks((int)(c->mA / 16 / wg_strips(c)), (int)(c->nA / 16), NB, slotsW, ns, cus, /*one_round_ok=*/false, &c->chunksW, &c->CH_W);
   const std::vector<int> bH = chunk_boundaries((int)(c->mA / 16), c->CH_H);
   const std::vector<int> bW = chunk_boundaries((int)(c->nA / 16), c->CH_W);
   c->chunksH = (int)bH.size() - 1;
