@@ -325,7 +325,6 @@ struct nbmf_ctx {
   bool factors_in_range = false;   // W >= 0 with column sums <= 1 + 1e-12, 0 <= H <= 1 - 1e-9 when they were set: Theta stays in [0, 1) for good
   int chunksH = 0, CH_H = 0, chunksW = 0, CH_W = 0;
   int *cstartH = nullptr, *cstartW = nullptr;   // device: chunk boundaries of the two sweeps
-  int gradedH = 0, gradedW = 0;                 // EXPERIMENT (NBMF_GRADED): classes of the graded one-round sweeps, 0 = off
   double *slabH = nullptr, *slabW = nullptr, *Pbuf = nullptr, *lossbuf = nullptr, *prior = nullptr, *scal = nullptr;
   double* lossfin = nullptr;   // the slots of the fused loss assembly (PassFin): LL_EMPTY in every slot between sweeps
   int n_prior_blocks = 0;
@@ -1198,7 +1197,6 @@ int enqueue_theta(nbmf_ctx* c, int image) {
     a.Rb = (int)((image == 0 ? c->mA : c->nA) / 16);
     a.Cb = (int)((image == 0 ? c->nA : c->mA) / 16);
     a.chunk_start = image == 0 ? c->cstartH : c->cstartW;
-    a.graded = image == 0 ? c->gradedH : c->gradedW;
     a.C_alloc = image == 0 ? c->nA : c->mA;
     a.eps = c->eps;
     a.tiny_eps = c->eps < 1e-70;
@@ -1230,7 +1228,6 @@ int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int cli
     a.Rb = (int)(c->mA / 16);
     a.Cb = (int)(c->nA / 16);
     a.chunk_start = c->cstartH;
-    a.graded = c->gradedH;
     a.C_alloc = c->nA;
     a.eps = c->eps;
     a.tiny_eps = tiny_a(c);
@@ -1310,7 +1307,6 @@ int enqueue_h_pass(nbmf_ctx* c, int fin_t = -1, double tol = 0.0) {
   a.Rb = (int)(c->mA / 16);
   a.Cb = (int)(c->nA / 16);
   a.chunk_start = c->cstartH;
-  a.graded = c->gradedH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c);
@@ -1345,7 +1341,6 @@ int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0, int fin_t = -1, d
   a.Rb = (int)(c->mA / 16);
   a.Cb = (int)(c->nA / 16);
   a.chunk_start = c->cstartH;
-  a.graded = c->gradedH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c);
@@ -1419,7 +1414,6 @@ PassArgs w_pass_args(nbmf_ctx* c) {
   a.Rb = (int)(c->nA / 16);
   a.Cb = (int)(c->mA / 16);
   a.chunk_start = c->cstartW;
-  a.graded = c->gradedW;
   a.C_alloc = c->mA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c) || c->w_free;   // (transform's W steps start from a W that is not on the simplex: the select variant)
@@ -1502,7 +1496,6 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   a.Rb = (int)(c->mA / 16);
   a.Cb = (int)(c->nA / 16);
   a.chunk_start = c->cstartH;
-  a.graded = c->gradedH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c);
@@ -1635,7 +1628,6 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
   a.Rb = (int)(c->mA / 16);
   a.Cb = (int)(c->nA / 16);
   a.chunk_start = c->cstartH;
-  a.graded = c->gradedH;
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c);
@@ -2292,53 +2284,10 @@ int setup_workspaces(nbmf_ctx* c) {
     if (*p) HIPCHK(dfree(*p));
     *p = nullptr;
   }
-  // EXPERIMENT NBMF_GRADED="s0,s1,s2,s3" (per mille of a strip's row blocks for the workgroup classes 0..R-1, R = the values
-  // given): one-round sweeps of exactly 8 chunks whose workgroups fill the chip R per CU get chunk sizes by class
-  auto graded_table = [&](const std::vector<int>& eq, int strips_groups, int Rb, int NBk, int* classes) -> std::vector<int> {
-    *classes = 0;
-    const char* e = getenv("NBMF_GRADED");
-    const int chunks = (int)eq.size() - 1;
-    if (!e || chunks != 8 || is_sharded(c) || c->KS > 1) return eq;
-    std::vector<double> w;
-    for (const char* q = e; *q;) {
-      w.push_back(atof(q));
-      while (*q && *q != ',') ++q;
-      if (*q == ',') ++q;
-    }
-    const int R = (int)w.size();
-    if (R < 2 || R > 4 || 8 % R != 0 || strips_groups % R != 0 || (long long)strips_groups * 8 != (long long)R * cus) return eq;
-    double tot = 0;
-    for (double v : w) tot += v;
-    std::vector<int> size(R);
-    int used = 0;
-    for (int i = 0; i < R; ++i) {
-      size[i] = (int)(w[i] / tot * Rb / (8 / R) / NBk + 0.5) * NBk;
-      used += size[i] * (8 / R);
-    }
-    size[R - 1] += (Rb - used) / (8 / R);   // (what rounding left over goes to the slowest class)
-    std::vector<int> tab;
-    for (int rot = 0; rot < R; ++rot) {
-      int pos = 0;
-      tab.push_back(0);
-      for (int ch = 0; ch < 8; ++ch) {
-        pos += size[((rot - ch) % R + R) % R];
-        tab.push_back(ch == 7 ? Rb : std::min(pos, Rb));
-      }
-    }
-    *classes = R;
-    if (getenv("NBMF_DEBUG")) {
-      fprintf(stderr, "[nbmf] graded chunks (%d classes):", R);
-      for (int v : size) fprintf(stderr, " %d", v);
-      fprintf(stderr, " row blocks\n");
-    }
-    return tab;
-  };
-  const std::vector<int> tH = graded_table(bH, (int)(c->nA / 16 / wg_strips(c)), (int)(c->mA / 16), NB, &c->gradedH);
-  const std::vector<int> tW = graded_table(bW, (int)(c->mA / 16 / wg_strips(c)), (int)(c->nA / 16), NB, &c->gradedW);
-  HIPCHK(dmalloc(&c->cstartH, sizeof(int) * tH.size()));
-  HIPCHK(dmalloc(&c->cstartW, sizeof(int) * tW.size()));
-  HIPCHK(hipMemcpy(c->cstartH, tH.data(), sizeof(int) * tH.size(), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->cstartW, tW.data(), sizeof(int) * tW.size(), hipMemcpyHostToDevice));
+  HIPCHK(dmalloc(&c->cstartH, sizeof(int) * bH.size()));
+  HIPCHK(dmalloc(&c->cstartW, sizeof(int) * bW.size()));
+  HIPCHK(hipMemcpy(c->cstartH, bH.data(), sizeof(int) * bH.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->cstartW, bW.data(), sizeof(int) * bW.size(), hipMemcpyHostToDevice));
   if (getenv("NBMF_DEBUG"))
     fprintf(stderr, "[nbmf] K_pad=%d path=%d: H-pass %d x %d workgroups (chunk %d blocks, %d slots), W-pass %d x %d (chunk %d, %d slots)\n",
             c->KP, c->data_kind, (int)(c->nA / 64), c->chunksH, c->CH_H, slotsH, (int)(c->mA / 64), c->chunksW, c->CH_W, slotsW);
