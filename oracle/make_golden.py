@@ -4,7 +4,7 @@
 Run in the build container only:  python oracle/make_golden.py
 It imports ``nbmf_mm`` from /root/reference/src (never copied into this repo) and stores
 inputs (when not regenerable from a seed) and the reference's outputs as small fixtures.
-The case list is SURVEY.md §8c items 1-9, plus (item 10, round 4) storage paths and input kinds beyond them.  The GPU box never runs this script.
+The case list is SURVEY.md §8c items 1-9, plus (item 10, round 4) storage paths and input kinds beyond them and (item 11, round 5) real-valued data at K = 16 / 32 / 64 and columns without a one under a flat prior.  The GPU box never runs this script.
 """
 import os
 import sys
@@ -182,6 +182,34 @@ def main():
     ex["dirbeta_transform"] = md.transform(Xb[:12].astype(np.float64))
     ex["dirbeta_H"] = md.components_
     np.savez_compressed(os.path.join(OUT, "round4.npz"), **ex)
+
+    # 11. round-5 additions: real-valued data at the component counts whose sweeps round 5 touched -- K = 16 (one 16-block
+    #     per strip: the shared reciprocal there is new), K = 32, K = 64 -- plain, with a bool mask under dir-beta, with real
+    #     weights; factors for the two small K, curves for all.  And the one-step update of a matrix with columns nobody has
+    #     a one in under a flat prior (alpha = 1: the numerator H * P1 + a is an exact 0 there, the update lands on the clip).
+    g5 = np.random.default_rng(55)
+    r5 = {}
+    Xr5 = g5.random((150, 170))
+    Br5 = g5.random((150, 170)) < 0.85
+    Wt5 = g5.random((150, 170))
+    for name, K5, orient, mk, its in (("k16_plain", 16, "beta-dir", None, 40), ("k16_mask_db", 16, "dir-beta", Br5, 40),
+                                      ("k32_weights", 32, "beta-dir", Wt5, 30), ("k64_mask", 64, "beta-dir", Br5, 20)):
+        m11 = NBMF(n_components=K5, alpha=1.2, beta=1.4, random_state=9, max_iter=its, tol=0, orientation=orient).fit(Xr5, mask=mk)
+        r5[name + "_losses"] = np.array(m11.loss_curve_)
+        if K5 <= 32:
+            r5[name + "_W"], r5[name + "_H"] = m11.W_, m11.components_
+    Yz = (g5.random((96, 70)) < 0.3).astype(np.float64)
+    Yz[:, 5] = 0.0
+    Yz[:, 11] = 0.0
+    Wz = g5.uniform(0.1, 0.9, (7, 96))
+    Wz /= Wz.sum(axis=0, keepdims=True)
+    Hz = g5.uniform(0.1, 0.9, (7, 70))
+    Mz = (g5.random((96, 70)) < 0.8).astype(np.float64)
+    r5["zc_Y"], r5["zc_W"], r5["zc_H"], r5["zc_mask"] = Yz, Wz, Hz, Mz
+    for tag, mk in (("plain", None), ("masked", Mz)):
+        Wn, Hn = nbmf_mm_update_beta_dir(Yz, Wz, Hz, mk, 1.0, 1.3, 1e-8)
+        r5["zc_W_new_" + tag], r5["zc_H_new_" + tag] = Wn, Hn
+    np.savez_compressed(os.path.join(OUT, "round5.npz"), **r5)
 
     print("golden fixtures written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):

@@ -628,6 +628,32 @@ def test_round4_reference_fixtures(hip, golden, both_small_paths):
     np.testing.assert_allclose(got[keep], g["dirbeta_transform"][keep], rtol=0, atol=FACTOR_ATOL)
 
 
+def test_round5_reference_fixtures(hip, golden, both_small_paths):
+    """The reference's own outputs (tests/golden/round5.npz) for real-valued data at K = 16 / 32 / 64 -- the register layouts
+    of the general path's sweeps round 5 touched: the shared reciprocal at K = 16, the range check left to the TINY variant
+    -- plain, with a bool mask under dir-beta, with real weights; and its one-step update of a matrix with columns nobody
+    has a one in under a flat prior (binary path: the H sweep's P1 is a difference of all-entry sums there)."""
+    from nbmf_mm_amd import NBMF
+    g = golden("round5")
+    g5 = np.random.default_rng(55)
+    Xr5 = g5.random((150, 170))
+    Br5 = g5.random((150, 170)) < 0.85
+    Wt5 = g5.random((150, 170))
+    for name, K, orient, mk, its in (("k16_plain", 16, "beta-dir", None, 40), ("k16_mask_db", 16, "dir-beta", Br5, 40),
+                                     ("k32_weights", 32, "beta-dir", Wt5, 30), ("k64_mask", 64, "beta-dir", Br5, 20)):
+        m = NBMF(n_components=K, alpha=1.2, beta=1.4, random_state=9, max_iter=its, tol=0, orientation=orient).fit(Xr5, mask=mk)
+        np.testing.assert_allclose(m.loss_curve_, g[name + "_losses"], rtol=LOSS_RTOL, atol=0, err_msg=name)
+        if K <= 32:
+            np.testing.assert_allclose(m.W_, g[name + "_W"], rtol=0, atol=FACTOR_ATOL, err_msg=name)
+            np.testing.assert_allclose(m.components_, g[name + "_H"], rtol=0, atol=FACTOR_ATOL, err_msg=name)
+    for tag, mk in (("plain", None), ("masked", g["zc_mask"])):
+        Wn, Hn, loss, binpath = _one_step(hip, g["zc_Y"], g["zc_W"], g["zc_H"], mk, 1.0, 1.3)
+        assert binpath
+        np.testing.assert_allclose(Hn, g["zc_H_new_" + tag], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(Wn, g["zc_W_new_" + tag], rtol=0, atol=1e-13)
+        assert (Hn[:, [5, 11]] == 1e-8).all()
+
+
 def _vs_oracle(Y, k, mask=None, iters=15, **kw):
     from nbmf_mm_amd import nbmf_mm_solver
     W, H, l, _, n1 = nbmf_mm_solver(Y, k, max_iter=iters, tol=0, mask=mask, **kw)

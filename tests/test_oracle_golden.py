@@ -224,3 +224,35 @@ def test_round4_fixtures_real_valued_paths_and_input_kinds(golden):
     np.testing.assert_array_equal(Hd, g["dirbeta_H"])
     np.random.seed(8)
     np.testing.assert_array_equal(orc.w_only_transform(Xf[:12], Hd), g["dirbeta_transform"])
+
+
+def _round5_inputs():
+    g5 = np.random.default_rng(55)
+    Xr5 = g5.random((150, 170))
+    Br5 = g5.random((150, 170)) < 0.85
+    Wt5 = g5.random((150, 170))
+    return Xr5, Br5, Wt5
+
+
+ROUND5_CASES = (("k16_plain", 16, "beta-dir", None, 40), ("k16_mask_db", 16, "dir-beta", "bool", 40),
+                ("k32_weights", 32, "beta-dir", "weights", 30), ("k64_mask", 64, "beta-dir", "bool", 20))
+
+
+def test_round5_fixtures_real_valued_data_at_k16_k32_k64_and_columns_without_a_one(golden):
+    """Item 11 of the fixture list: the REFERENCE's fits of real-valued data at K = 16, 32 and 64 (plain, bool mask under
+    dir-beta, real weights) and its one-step update of a matrix with two columns nobody has a one in under alpha = 1 (an
+    exact 0 in the numerator: the update lands on the lower clip).  The restatement meets all of it bitwise."""
+    g = golden("round5")
+    Xr5, Br5, Wt5 = _round5_inputs()
+    for name, K, orient, mk, its in ROUND5_CASES:
+        mask = None if mk is None else (Br5.astype(np.float64) if mk == "bool" else Wt5)
+        W, H, losses, _, _ = orc.solve(Xr5, K, alpha=1.2, beta=1.4, random_state=9, max_iter=its, tol=0, orientation=orient, mask=mask)
+        np.testing.assert_array_equal(np.array(losses), g[name + "_losses"])
+        if K <= 32:
+            np.testing.assert_array_equal(W, g[name + "_W"])
+            np.testing.assert_array_equal(H, g[name + "_H"])
+    for tag, mk in (("plain", None), ("masked", g["zc_mask"])):
+        Wn, Hn = orc.mm_step(g["zc_Y"], g["zc_W"], g["zc_H"], mk, 1.0, 1.3)
+        np.testing.assert_array_equal(Wn, g["zc_W_new_" + tag])
+        np.testing.assert_array_equal(Hn, g["zc_H_new_" + tag])
+        assert (g["zc_H_new_" + tag][:, [5, 11]] == 1e-8).all()      # the clip's lower end, exactly
