@@ -762,7 +762,7 @@ hipError_t log_table_device(const double2** out) {
 // configs[1] cost ~4.5 us each, 5 % of the iteration); EvScope puts them here, the next pass launch of this thread
 // takes them.  Sweeps of several launches are bracketed by recorded events as before.
 thread_local hipEvent_t tl_attach_start = nullptr, tl_attach_stop = nullptr;
-template <int KB, int DATA, int MODE, int TH, bool TINY>
+template <int KB, int DATA, int MODE, int TH, bool TINY, bool RAG = false>
 hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
   dim3 grid(a_.Cb / WG_WAVES, chunks);
   constexpr int lds_bytes = pass_lds_bytes(KB, DATA, MODE);
@@ -788,7 +788,7 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
     hipError_t e = dmalloc(&tr, sizeof(unsigned long long) * 8 * n_wg);
     if (e != hipSuccess) return e;
     a.trace = tr;
-    hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
+    hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY, RAG>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
     std::vector<unsigned long long> h(8 * n_wg);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -843,16 +843,30 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
   if (tl_attach_start) {
     hipEvent_t e0 = tl_attach_start, e1 = tl_attach_stop;
     tl_attach_start = tl_attach_stop = nullptr;
-    hipExtLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, e0, e1, 0, a);
+    hipExtLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY, RAG>), grid, dim3(64 * WG_WAVES), lds_bytes, st, e0, e1, 0, a);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
+  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY, RAG>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
   return hipGetLastError();
 }
 // (eps below 1e-70 on the binary path: the variant with per-entry reciprocals and renormalisation, see pass_kernel)
 template <int KB, int DATA, int MODE, int TH = 0>
 hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
   if (MODE != MODE_T && a.tiny_eps) return launch_pass_tt<KB, DATA, MODE, TH, MODE != MODE_T>(a, chunks, st);
+  // Fewer components than the layout holds -- 10 in the K = 16 layout, 40 in the K = 64 one: the variant that skips the
+  // k-steps and 16-blocks of components that are padding (RAG, nbmf_pass_kernel.inc).  Where it pays (measured, 32768 x 8192,
+  // byte codes: k = 4 +19 %, 8 +11-16 %, 10-12 +2-6 %, 20 +9 %, 24 +5 %, 40 +20 %, 48 +15 %): up to the K = 64 layout -- at
+  // K = 128 the branches cost the register-tuned schedule more than the skipped MFMAs give back (k = 100: -4.6 %) --, when
+  // at least a twelfth of the tile's MFMAs goes (k = 50: three of 48, -1.7 %), and not on the general path at K <= 16 (four
+  // tiles per stage with branches between their MFMAs: 250 registers and scratch, -4 % at k = 10).
+  constexpr bool HAS_RAG = TH == 0 && MODE != MODE_T && KB <= 4 && (DATA == DATA_BIN || KB >= 2);
+  static const bool no_rag = getenv("NBMF_NO_RAGGED_K") != nullptr;   // (tests: the full-K kernels on a ragged K -- the same bits)
+  if (HAS_RAG && !no_rag && a.ksteps > 0 && a.ksteps < 4 * KB) {
+    const int per_block = MODE == MODE_H ? 8 : (MODE == MODE_W ? 4 : 0);   // back-product MFMAs of one 16-block of components
+    const int skipped = (4 * KB - a.ksteps) + (KB >= 4 ? (KB - a.kblocks) * per_block : 0);
+    const int total = 4 * KB + KB * per_block;
+    if (12 * skipped >= total) return launch_pass_tt<KB, DATA, MODE, TH, false, HAS_RAG>(a, chunks, st);
+  }
   return launch_pass_tt<KB, DATA, MODE, TH, false>(a, chunks, st);
 }
 
@@ -1231,6 +1245,8 @@ int enqueue_a_sweeps_sliced(nbmf_ctx* c, bool with_products, int strict, int cli
     a.C_alloc = c->nA;
     a.eps = c->eps;
     a.tiny_eps = tiny_a(c);
+    a.ksteps = (c->k + 3) / 4;
+    a.kblocks = (c->k + 15) / 16;
     a.strict = strict;
     a.clip = clip;
     a.theta = c->theta;
@@ -1310,6 +1326,8 @@ int enqueue_h_pass(nbmf_ctx* c, int fin_t = -1, double tol = 0.0) {
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c);
+  a.ksteps = (c->k + 3) / 4;
+  a.kblocks = (c->k + 15) / 16;
   if (fin_t >= 0) fin_fill(c, a, fin_t, tol, 0);
   {
     EvScope ev(c, 0, true, /*attach=*/true);
@@ -1344,6 +1362,8 @@ int enqueue_loglik_pass(nbmf_ctx* c, int strict, int clip = 0, int fin_t = -1, d
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c);
+  a.ksteps = (c->k + 3) / 4;
+  a.kblocks = (c->k + 15) / 16;
   a.strict = strict;
   a.clip = clip;
   if (fin_t >= 0) fin_fill(c, a, fin_t, tol, strict);
@@ -1417,6 +1437,8 @@ PassArgs w_pass_args(nbmf_ctx* c) {
   a.C_alloc = c->mA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c) || c->w_free;   // (transform's W steps start from a W that is not on the simplex: the select variant)
+  a.ksteps = (c->k + 3) / 4;
+  a.kblocks = (c->k + 15) / 16;
   return a;
 }
 
@@ -1499,6 +1521,8 @@ int enqueue_iteration_rows_peer(nbmf_ctx* c, int it, double tol) {
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c);
+  a.ksteps = (c->k + 3) / 4;
+  a.kblocks = (c->k + 15) / 16;
   {
     EvScope ev(c, 0, true, /*attach=*/c->KS == 1);
     if (c->KS > 1) {
@@ -1631,6 +1655,8 @@ int enqueue_iteration_rows(nbmf_ctx* c, int it, double tol) {
   a.C_alloc = c->nA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c);
+  a.ksteps = (c->k + 3) / 4;
+  a.kblocks = (c->k + 15) / 16;
   {
     EvScope ev(c, 0, true, /*attach=*/true);
     HIPCHK(launch_pass<MODE_H>(c->KB, c->data_kind, a, c->chunksH, s0));

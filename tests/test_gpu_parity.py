@@ -2,6 +2,8 @@
 vectors, same seeded inputs.  Tolerances: loss curve <= 1e-10 relative per point,
 factors <= 1e-9 absolute, final NLL <= 1e-8 relative (north star), monotone within 1e-12.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -652,6 +654,48 @@ def test_round5_reference_fixtures(hip, golden, both_small_paths):
         np.testing.assert_allclose(Hn, g["zc_H_new_" + tag], rtol=0, atol=1e-13)
         np.testing.assert_allclose(Wn, g["zc_W_new_" + tag], rtol=0, atol=1e-13)
         assert (Hn[:, [5, 11]] == 1e-8).all()
+
+
+_RAGGED_SCRIPT = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from nbmf_mm_amd import nbmf_mm_solver
+g = np.random.default_rng(33)
+Xb = (g.random((700, 520)) < 0.3).astype(np.float64)
+Xr = g.random((700, 520))
+mk = g.random((700, 520)) < 0.85
+out = {}
+for name, X, K in (("bin5", Xb, 5), ("bin8", Xb, 8), ("bin10", Xb, 10), ("bin20", Xb, 20), ("bin40", Xb, 40), ("bin48", Xb, 48),
+                   ("real20", Xr, 20), ("real40", Xr, 40)):
+    W, H, l, _, _ = nbmf_mm_solver(X, K, max_iter=12, tol=0, random_state=1, mask=mk, alpha=1.2, beta=1.3)
+    out[name] = [np.asarray(l).tobytes().hex(), W.tobytes().hex()[:4096], H.tobytes().hex()[:4096], float(l[-1])]
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_ragged_k_variant_gives_the_full_kernels_bits(hip):
+    """Fewer components than the layout holds (k = 10 in the K = 16 layout, 40 in the K = 64 one): the sweeps' RAG variant
+    skips the Theta k-steps and the 16-blocks of components that hold nothing but padding.  The padding is exact zeros in both
+    factors, so the skipped MFMAs would have added zeros: the fit must be the full kernels' (NBMF_NO_RAGGED_K=1) BIT FOR
+    BIT -- losses, W, H -- on byte-code and real-valued data, where the variant is used and where it is not."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for no_rag in (False, True):
+        env = dict(os.environ, NBMF_PERSISTENT="0")
+        env.pop("NBMF_NO_RAGGED_K", None)
+        if no_rag:
+            env["NBMF_NO_RAGGED_K"] = "1"
+        r = subprocess.run([sys.executable, "-c", _RAGGED_SCRIPT, root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        res.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]))
+    assert res[0].keys() == res[1].keys() and len(res[0]) == 8
+    for name in res[0]:
+        assert res[0][name] == res[1][name], name
+        assert np.isfinite(res[0][name][3])
 
 
 def _vs_oracle(Y, k, mask=None, iters=15, **kw):
