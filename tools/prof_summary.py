@@ -9,12 +9,13 @@ import sys
 
 
 def short(name):
-    m = re.search(r"pass_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?(?:, (true|false))?>", name)
+    m = re.search(r"pass_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?(?:, (true|false))?(?:, (true|false))?>", name)
     if m:
         kb, data, mode = map(int, m.groups()[:3])
         th = ",Theta-in" if m.group(4) and int(m.group(4)) else ""
         tiny = ",tiny-eps" if m.group(5) == "true" else ""
-        return f"pass_kernel<K={16*kb},{['BIN','F64','F64M'][data]},{'HWLT'[mode]}{th}{tiny}>"
+        rag = ",ragged-K" if m.group(6) == "true" else ""
+        return f"pass_kernel<K={16*kb},{['BIN','F64','F64M'][data]},{'HWLT'[mode]}{th}{tiny}{rag}>"
     m = re.search(r"(\w+_kernel|__amd_rocclr_\w+)", name)
     return m.group(1) if m else name[:40]
 
