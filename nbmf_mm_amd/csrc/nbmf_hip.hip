@@ -71,6 +71,11 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
   g_err = buf;
+  // A failed runtime call also leaves its code in the thread's "last error", which stays until somebody reads it: the
+  // next launch check (HIPCHK(hipGetLastError())) of this thread -- in this context or any other -- would report it as its
+  // own (an upload that ran out of memory made the NEXT, small, fit fail with "out of memory": tests/test_gpu_lifecycle.py).
+  // Reading it here resets it.
+  if (code == NBMF_ERR_HIP) (void)hipGetLastError();
   return code;
 }
 
@@ -459,6 +464,7 @@ hipError_t dmalloc(T** out, size_t bytes) {
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, key.bytes);
   if (e != hipSuccess) {   // out of memory: give back what is held and try once more
+    (void)hipGetLastError();   // (the failed attempt's code must not outlive a retry that succeeds: see fail())
     std::vector<void*> drop;
     {
       std::lock_guard<std::mutex> lk(g_pool.mu);

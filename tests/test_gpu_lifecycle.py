@@ -67,10 +67,13 @@ def _one_fit(hip, V, mask, k, iters, storage="auto"):
 
 def test_the_probe_sees_a_live_context(hip):
     """(The measurement itself: a live 4096 x 4096 context on the 8-byte path holds two 128 MiB images, and the probe
-    says so -- the tests below would see a leak of one.)"""
+    says so -- the tests below would see a leak of one.  Blocks of up to 64 MiB stay with the library's pool when a
+    context goes -- nbmf_hip.hip, `dmalloc` / `dfree`: up to NBMF_POOL_MB = 1 GiB, handed to the next context that asks
+    for the size -- so every test here takes its base line after one round of what it repeats.)"""
     g = np.random.default_rng(5)
     V = g.random((4096, 4096))
-    _one_fit(hip, V[:256, :256], None, 8, 2)
+    with hip.Context(4096, 4096, 16) as ctx:
+        ctx.upload(V, None)
     gc.collect()
     base = _free_bytes(hip)
     with hip.Context(4096, 4096, 16) as ctx:
@@ -197,3 +200,62 @@ def test_sharded_fits_give_their_arenas_back_or_reuse_them():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert out["same"] is True
     assert abs(out["moved"]) <= 16 << 20, f"device memory moved by {out['moved'] / 2**20:.1f} MiB over 6 sharded fits"
+
+
+def test_a_problem_that_does_not_fit_is_an_error_and_costs_nothing(hip):
+    """4 194 304 x 49 152 binary entries generated on the device would need ~410 GB of tile codes: the upload fails with
+    the library's error (no crash, no abort), the context can be destroyed, what it had allocated before the failure
+    comes back, and the next fit on the device is the usual one."""
+    g = np.random.default_rng(6)
+    V = (g.random((512, 384)) < 0.3).astype(np.float64)
+    want = _one_fit(hip, V, None, 16, 4)
+    gc.collect()
+    base = _free_bytes(hip)
+    ctx = hip.Context(4194304, 49152, 16)
+    try:
+        with pytest.raises(hip.NBMFHipError, match="(?i)memory|alloc"):
+            ctx.generate(seed=1, density=0.25, observed=0.9)
+    finally:
+        ctx.close()
+    gc.collect()
+    assert abs(base - _free_bytes(hip)) <= 256 << 20                      # (pooled blocks of the failed context's factors: <= 64 MiB each)
+    assert _one_fit(hip, V, None, 16, 4) == want
+
+
+def test_a_context_used_again_is_a_fresh_one(hip):
+    """One context, six uploads in a row -- byte codes, doubles with a folded mask, doubles with weight tiles, byte codes
+    with a mask, the first again, hyper-parameters and projection changed in between, evaluation calls in between: every
+    fit has the bits of the same fit in a context of its own (nothing of an earlier upload -- storage kind, lane masks,
+    row counts, the factors' range check, stop flags, the loss carried into the next sweep -- survives the next one).
+    Both engines: the 200 x 160 problems run in the single launch, the 1408 x 1152 ones in the five kernels."""
+    g = np.random.default_rng(8)
+    for (m, n, k) in [(200, 160, 6), (1408, 1152, 32)]:
+        Vb = (g.random((m, n)) < 0.3).astype(np.float64)
+        Vr = g.random((m, n))
+        Mb = g.random((m, n)) < 0.85
+        Mw = g.random((m, n))
+        W0 = g.random((k, m))
+        W0 /= W0.sum(axis=0, keepdims=True)
+        H0 = g.uniform(0.1, 0.9, (k, n))
+        steps = [(Vb, None, 1.2, 1.2, 0), (Vr, Mb, 1.0, 1.5, 1), (Vr, Mw, 2.0, 1.2, 0), (Vb, Mb, 1.2, 1.2, 1),
+                 (Vb, None, 1.2, 1.2, 0), (Vr, None, 1.1, 1.1, 0)]
+
+        def fit(ctx, V, M, al, be, proj, iters):
+            ctx.set_hyper(al, be, 1e-8, proj)
+            ctx.upload(V, M)
+            ctx.set_factors(W0, H0)
+            losses, n_iter = ctx.run(iters, 1e-7)
+            W, H = ctx.get_factors()
+            return losses.tobytes(), n_iter, W.tobytes(), H.tobytes(), ctx.loss(), ctx.loglik()
+
+        fresh = []
+        for (V, M, al, be, proj) in steps:
+            with hip.Context(m, n, k) as ctx:
+                fresh.append(fit(ctx, V, M, al, be, proj, 12))
+        with hip.Context(m, n, k) as ctx:
+            for i, (V, M, al, be, proj) in enumerate(steps):
+                got = fit(ctx, V, M, al, be, proj, 12)
+                assert got == fresh[i], f"{m} x {n}: upload {i} differs from a context of its own"
+                ctx.w_only_steps(3)                                      # an evaluation-time call between two fits
+                ctx.loglik_strict()
+        assert fresh[0] == fresh[4]
