@@ -670,6 +670,22 @@ for name, X, K in (("bin5", Xb, 5), ("bin8", Xb, 8), ("bin10", Xb, 10), ("bin20"
                    ("real20", Xr, 20), ("real40", Xr, 40)):
     W, H, l, _, _ = nbmf_mm_solver(X, K, max_iter=12, tol=0, random_state=1, mask=mk, alpha=1.2, beta=1.3)
     out[name] = [np.asarray(l).tobytes().hex(), W.tobytes().hex()[:4096], H.tobytes().hex()[:4096], float(l[-1])]
+# ... real weights (the third storage path), the other orientation, the evaluation-time calls (transform = the W sweep with
+# H frozen, score / perplexity = the likelihood sweep, clipped and strict) and a four-rank fit (rank threads on device 0)
+import hashlib
+from nbmf_mm_amd import NBMF
+wts = g.uniform(0.2, 1.0, (700, 520)) * mk
+for name, X, K in (("realw20", Xr, 20), ("realw40", Xr, 40)):
+    W, H, l, _, _ = nbmf_mm_solver(X, K, max_iter=10, tol=0, random_state=2, mask=wts, orientation="dir-beta")
+    out[name] = [np.asarray(l).tobytes().hex(), hashlib.sha1(W.tobytes()).hexdigest(), hashlib.sha1(H.tobytes()).hexdigest(), float(l[-1])]
+for name, X, K in (("est_bin10", Xb, 10), ("est_bin40", Xb, 40), ("est_real24", Xr, 24)):
+    est = NBMF(n_components=K, max_iter=15, tol=0, random_state=3).fit(X, mask=mk)
+    T = est.transform(X[:130], mask=mk[:130])
+    out[name] = [hashlib.sha1(T.tobytes()).hexdigest(), repr(est.score(X, mask=mk)), repr(est.perplexity(X, mask=mk)),
+                 float(est.score(X[:64]))]
+est = NBMF(n_components=40, max_iter=10, tol=0, random_state=4, n_gpus=4, devices=[0] * 4).fit(Xb, mask=mk)
+out["four_ranks_bin40"] = [hashlib.sha1(est.W_.tobytes()).hexdigest(), hashlib.sha1(est.components_.tobytes()).hexdigest(),
+                           repr(est.reconstruction_err_), float(est.reconstruction_err_)]
 print("RESULT " + json.dumps(out))
 """
 
@@ -678,21 +694,22 @@ def test_ragged_k_variant_gives_the_full_kernels_bits(hip):
     """Fewer components than the layout holds (k = 10 in the K = 16 layout, 40 in the K = 64 one): the sweeps' RAG variant
     skips the Theta k-steps and the 16-blocks of components that hold nothing but padding.  The padding is exact zeros in both
     factors, so the skipped MFMAs would have added zeros: the fit must be the full kernels' (NBMF_NO_RAGGED_K=1) BIT FOR
-    BIT -- losses, W, H -- on byte-code and real-valued data, where the variant is used and where it is not."""
+    BIT -- losses, W, H -- on byte-code and real-valued data (folded mask, real weights), where the variant is used and where it
+    is not; and so must transform, score and perplexity (the W sweep with H frozen, the likelihood sweep) and a four-rank fit."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
     for no_rag in (False, True):
-        env = dict(os.environ, NBMF_PERSISTENT="0")
+        env = dict(os.environ, NBMF_PERSISTENT="0", GPU_MAX_HW_QUEUES="32", NBMF_PEER_TIMEOUT_MS="20000")
         env.pop("NBMF_NO_RAGGED_K", None)
         if no_rag:
             env["NBMF_NO_RAGGED_K"] = "1"
         r = subprocess.run([sys.executable, "-c", _RAGGED_SCRIPT, root], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
         res.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]))
-    assert res[0].keys() == res[1].keys() and len(res[0]) == 8
+    assert res[0].keys() == res[1].keys() and len(res[0]) == 14
     for name in res[0]:
         assert res[0][name] == res[1][name], name
         assert np.isfinite(res[0][name][3])
