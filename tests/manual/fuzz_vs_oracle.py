@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep against the oracle (hand-run on a GPU box: `python tests/manual/fuzz_vs_oracle.py [cases] [seed]`).
+"""Randomised parity sweep against the oracle (hand-run on a GPU box: `python tests/manual/fuzz_vs_oracle.py [cases] [seed] [max_dim]`).
 
 Every case draws a shape, K, data kind (binary / real), mask kind (none / bool / real weights), orientation,
 hyper-parameters, eps, the projection (the reference's or the Duchi extension), an init that is in or out of the range a
@@ -75,11 +75,13 @@ def run(cases, seed, max_dim=700):
             dW = np.max(np.abs(W - Wr)) if np.all(np.isfinite(Wr)) else float("nan")
             print(f"case {case}: MISMATCH rel loss {dl:.2e} max|dW| {dW:.2e}  m={m} n={n} k={k} real={real} mask={mk} init={init} eps={eps_kind} "
                   f"{kw['orientation']} its={kw['max_iter']} engine={os.environ['NBMF_PERSISTENT']} duchi={duchi}", flush=True)
+        if case % 50 == 49:
+            print(f"  ... {case + 1} cases, {bad} failures, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
     return bad, time.time() - t0
 
 
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    n_bad, secs = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    n_bad, secs = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0, int(sys.argv[3]) if len(sys.argv) > 3 else 700)
     print(f"{n_cases} cases, {n_bad} failures, {secs:.0f} s")
     sys.exit(1 if n_bad else 0)
