@@ -312,6 +312,7 @@ def fit_in_process(V, n_components, n_gpus, devices=None, orientation="beta-dir"
         mask = mask.tocsr()
     M, N = V.shape
     K = int(n_components)
+    shard_bounds(M, n_gpus, 0)                       # (fewer rows than ranks: a ValueError here, not in the rank threads)
     transposed = orientation == "dir-beta"
     if orientation not in ("beta-dir", "dir-beta"):
         raise ValueError(f"Unknown orientation: {orientation}")
@@ -339,10 +340,10 @@ def fit_in_process(V, n_components, n_gpus, devices=None, orientation="beta-dir"
                 print(f"Iter {it:4d}: Loss = {loss:.6f}", flush=True)
 
     def body(r):
-        r0, r1 = shard_bounds(M, n_gpus, r)
         live = {"progress": _report} if (verbose > 0 and r == 0) else {}
         try:
-            with groups[r] as g:
+            with groups[r] as g:                                          # (whatever fails in here aborts the group: nobody waits for this rank)
+                r0, r1 = shard_bounds(M, n_gpus, r)
                 results[r] = rank_fit(V[r0:r1], (M, N), r0, K, g, orientation=orientation, shard="rows", max_iter=max_iter,
                                       tol=tol, alpha=alpha, beta=beta, W_init=W_user, H_init=H_user,
                                       mask_local=None if mask is None else mask[r0:r1], random_state=None, eps=eps,

@@ -615,6 +615,10 @@ def test_fit_in_process_splits_seeds_and_assembles_like_the_single_fit(orientati
         _dist.fit_in_process(V, K, n_gpus, devices=[0] * n_gpus, orientation=orientation, max_iter=5, tol=0, _rank_fit=failing)
     with pytest.raises(ValueError, match="devices names"):
         _dist.fit_in_process(V, K, n_gpus, devices=[0], _rank_fit=_oracle_rank_fit)
+    # fewer rows than ranks: refused in the caller's thread, before any rank starts (found by tests/manual/fuzz_sharded_vs_single.py:
+    # the rank threads died one by one and the caller got a TypeError out of their missing results)
+    with pytest.raises(ValueError, match=f"cannot shard {n_gpus - 1} rows over {n_gpus} ranks"):
+        _dist.fit_in_process(V[:n_gpus - 1], K, n_gpus, devices=[0] * n_gpus, _rank_fit=_oracle_rank_fit)
 
 
 def test_fit_in_process_verbose_reports_through_rank_zero_only(capsys):
