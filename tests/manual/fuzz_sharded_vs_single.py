@@ -53,6 +53,14 @@ def run(cases, seed, max_dim=900):
             kw["W_init"], kw["H_init"] = W0, H0
         transport = str(r.choice(["auto", "host"], p=[0.7, 0.3]))
         tag = f"{transport} m={m} n={n} k={k} ranks={ranks} data={kind} mask={mk} init={init} {kw['orientation']} {kw['projection']} its={kw['max_iter']} tol={kw['tol']}"
+        if m < ranks:                               # fewer rows than ranks: refused, cleanly
+            try:
+                fit_in_process(Y, k, ranks, devices=[0] * ranks, transport=transport, **kw)
+                bad += 1
+                print(f"case {case}: no ValueError  {tag}", flush=True)
+            except ValueError as e:
+                assert "cannot shard" in str(e)
+            continue
         try:
             with np.errstate(all="ignore"):
                 W1, H1, l1, _, n1 = nbmf_mm_solver(Y, k, **kw)

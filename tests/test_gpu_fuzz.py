@@ -29,3 +29,29 @@ def test_randomised_evaluation_calls_against_the_oracle():
     spec.loader.exec_module(fuzz)
     bad, _ = fuzz.run(250, 11, max_dim=700)
     assert bad == 0
+
+
+_SHARDED_FUZZ = r"""
+import importlib.util, os, sys
+root = sys.argv[1]
+sys.path.insert(0, root)
+spec = importlib.util.spec_from_file_location("fuzz_sharded_vs_single", os.path.join(root, "tests", "manual", "fuzz_sharded_vs_single.py"))
+fuzz = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(fuzz)
+bad, _ = fuzz.run(120, 5, max_dim=800)
+print("RESULT", bad)
+"""
+
+
+def test_randomised_sharded_fits_against_the_single_context_fit():
+    """... and of tests/manual/fuzz_sharded_vs_single.py: 2-6 rank threads on device 0 (peer or host transport), shapes down to
+    fewer rows than ranks (refused), shards that choose different storage paths, both orientations and projections, stop
+    rules -- against the fit of the whole matrix in one context (same iteration count, losses rtol 1e-10, factors atol 1e-9).
+    In a child process: the ranks' streams need hardware queues of their own, set before the runtime starts."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", NBMF_PEER_TIMEOUT_MS="20000")
+    r = subprocess.run([sys.executable, "-c", _SHARDED_FUZZ, root], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1] == "RESULT 0", r.stdout[-3000:]
