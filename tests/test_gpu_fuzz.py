@@ -55,3 +55,15 @@ def test_randomised_sharded_fits_against_the_single_context_fit():
     r = subprocess.run([sys.executable, "-c", _SHARDED_FUZZ, root], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1] == "RESULT 0", r.stdout[-3000:]
+
+
+def test_randomised_batches_against_one_run_per_problem():
+    """... and of tests/manual/fuzz_batch_vs_runs.py: `nbmf_run_batch` (P fits of one data set: a grid of priors, restarts)
+    against set_hyper + set_factors + run + get_factors per problem, BIT FOR BIT -- loss curves, iteration counts under
+    a stop rule that fires at different iterations for different problems, factors."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual", "fuzz_batch_vs_runs.py")
+    spec = importlib.util.spec_from_file_location("fuzz_batch_vs_runs", path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad, _ = fuzz.run(150, 9, max_dim=1200)
+    assert bad == 0
