@@ -26,6 +26,9 @@ def run(cases, seed, max_dim=700):
         k = int(r.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 129, 140]))
         real = r.random() < 0.25
         Y = r.random((m, n)) if real else (r.random((m, n)) < r.uniform(0.05, 0.9)).astype(np.float64)
+        as_f32 = real and r.random() < 0.33
+        if as_f32:
+            Y = Y.astype(np.float32).astype(np.float64)   # (the values the float32 array will hold, for the oracle)
         mk = r.choice(["none", "bool", "weights"], p=[0.4, 0.45, 0.15])
         mask = None if mk == "none" else ((r.random((m, n)) < r.uniform(0.3, 0.99)) if mk == "bool" else r.random((m, n)))
         kw = dict(max_iter=int(r.integers(1, 25)), tol=0, mask=mask, alpha=float(r.uniform(1.0, 2.0)), beta=float(r.uniform(1.0, 2.0)),
@@ -51,15 +54,49 @@ def run(cases, seed, max_dim=700):
         duchi = bool(r.random() < 0.25) and init in ("seed", "in_range")   # (the extension: Euclidean projection, README.md:27-35)
         with np.errstate(all="ignore"):
             Wr, Hr, lr, _, _ = orc.solve(Y, k, step=orc.mm_step_duchi if duchi else None, **kw)
-        # (round 4: binary data is handed over as bool / uint8 in a third of the cases -- one byte per entry, nbmf_upload_v)
+        # (round 4: binary data is handed over as bool / uint8 in a third of the cases -- one byte per entry, nbmf_upload_v;
+        #  round 5: as a scipy CSR matrix, Fortran-ordered or as a strided view in some; real data as float32 in a third --
+        #  the oracle then works on the float32 values, exactly representable -- and the mask as uint8 / float32 / CSR)
         Y_in = Y
+        form = "f64"
         if not real:
-            Y_in = {0: Y, 1: Y.astype(np.uint8), 2: Y.astype(bool)}[int(r.integers(0, 3))]
+            form = str(r.choice(["f64", "u8", "bool", "csr", "fortran", "strided"]))
+            if form == "u8":
+                Y_in = Y.astype(np.uint8)
+            elif form == "bool":
+                Y_in = Y.astype(bool)
+            elif form == "csr":
+                import scipy.sparse as sp
+                Y_in = sp.csr_matrix(Y)
+        else:
+            form = "f32" if as_f32 else str(r.choice(["f64", "fortran", "strided"]))
+            if form == "f32":
+                Y_in = Y.astype(np.float32)
+        if form == "fortran":
+            Y_in = np.asfortranarray(Y)
+        elif form == "strided":
+            big = np.zeros((2 * m, 2 * n), dtype=Y.dtype)
+            big[::2, ::2] = Y
+            Y_in = big[::2, ::2]
+        mask_in = mask
+        mform = "as-is"
+        if mask is not None:
+            mform = str(r.choice(["as-is", "u8", "f32", "csr"] if mk == "bool" else ["as-is", "fortran"]))
+            if mform == "u8":
+                mask_in = mask.astype(np.uint8)
+            elif mform == "f32":
+                mask_in = mask.astype(np.float32)
+            elif mform == "csr":
+                import scipy.sparse as sp
+                mask_in = sp.csr_matrix(mask.astype(np.float64))
+            elif mform == "fortran":
+                mask_in = np.asfortranarray(mask)
+        kw_in = dict(kw, mask=mask_in)
         try:
-            W, H, l, _, _ = nbmf_mm_solver(Y_in, k, projection="duchi" if duchi else "normalize", **kw)
+            W, H, l, _, _ = nbmf_mm_solver(Y_in, k, projection="duchi" if duchi else "normalize", **kw_in)
         except Exception as e:   # noqa: BLE001
             bad += 1
-            print(f"case {case}: EXCEPTION {e!r}  m={m} n={n} k={k} real={real} mask={mk} init={init} eps={eps_kind} {kw['orientation']}")
+            print(f"case {case}: EXCEPTION {e!r}  m={m} n={n} k={k} real={real} mask={mk} init={init} eps={eps_kind} {kw['orientation']} data as {form} mask as {mform}")
             continue
         lr = np.asarray(lr)
         l = np.asarray(l)
@@ -74,7 +111,7 @@ def run(cases, seed, max_dim=700):
             dl = np.max(np.abs(l[fin] / lr[fin] - 1)) if fin.any() else float("nan")
             dW = np.max(np.abs(W - Wr)) if np.all(np.isfinite(Wr)) else float("nan")
             print(f"case {case}: MISMATCH rel loss {dl:.2e} max|dW| {dW:.2e}  m={m} n={n} k={k} real={real} mask={mk} init={init} eps={eps_kind} "
-                  f"{kw['orientation']} its={kw['max_iter']} engine={os.environ['NBMF_PERSISTENT']} duchi={duchi}", flush=True)
+                  f"{kw['orientation']} its={kw['max_iter']} engine={os.environ['NBMF_PERSISTENT']} duchi={duchi} data as {form} mask as {mform}", flush=True)
         if case % 50 == 49:
             print(f"  ... {case + 1} cases, {bad} failures, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
     return bad, time.time() - t0
