@@ -4,7 +4,7 @@
 Run in the build container only:  python oracle/make_golden.py
 It imports ``nbmf_mm`` from /root/reference/src (never copied into this repo) and stores
 inputs (when not regenerable from a seed) and the reference's outputs as small fixtures.
-The case list is SURVEY.md §8c items 1-9, plus (item 10, round 4) storage paths and input kinds beyond them and (item 11, round 5) real-valued data at K = 16 / 32 / 64 and columns without a one under a flat prior.  The GPU box never runs this script.
+The case list is SURVEY.md §8c items 1-9, plus (item 10, round 4) storage paths and input kinds beyond them and (item 11, round 5) real-valued data at K = 16 / 32 / 64 and columns without a one under a flat prior, and (item 12) twenty random fits through the estimator.  The GPU box never runs this script.
 """
 import os
 import sys
@@ -210,6 +210,45 @@ def main():
         Wn, Hn = nbmf_mm_update_beta_dir(Yz, Wz, Hz, mk, 1.0, 1.3, 1e-8)
         r5["zc_W_new_" + tag], r5["zc_H_new_" + tag] = Wn, Hn
     np.savez_compressed(os.path.join(OUT, "round5.npz"), **r5)
+
+    # 12. twenty random fits THROUGH THE ESTIMATOR (round 5): shapes 3..60, K 1..12, binary / real-valued data handed over as
+    #     float64 / int / bool / float32 / CSR, no mask / bool / 0-1 float / real weights, every orientation alias of
+    #     _base.py:126-136, priors in [1, 3], seeded or custom inits (one or both), a stop rule that fires or not.  Inputs
+    #     and parameters are stored with the reference's W_, components_, loss_curve_, n_iter_.
+    import json
+    import scipy.sparse as sp
+    g12 = np.random.default_rng(1212)
+    aliases = ["beta-dir", "dir-beta", "Beta-Dir", "Dir-Beta", "Dir Beta", "binary ICA", "Binary ICA", "bICA", "Aspect Bernoulli"]
+    est = {"n_cases": np.array(20)}
+    for i in range(20):
+        m12, n12, k12 = int(g12.integers(3, 61)), int(g12.integers(3, 61)), int(g12.integers(1, 13))
+        real = bool(g12.random() < 0.35)
+        X12 = g12.random((m12, n12)) if real else (g12.random((m12, n12)) < g12.uniform(0.1, 0.8)).astype(np.float64)
+        form = str(g12.choice(["f64", "f32"] if real else ["f64", "int", "bool", "f32", "csr"]))
+        if form == "f32":
+            X12 = X12.astype(np.float32).astype(np.float64)
+        mk = str(g12.choice(["none", "bool", "float01", "weights"], p=[0.35, 0.3, 0.15, 0.2]))
+        M12 = {"none": None, "bool": g12.random((m12, n12)) < 0.8, "float01": (g12.random((m12, n12)) < 0.7).astype(np.float64),
+               "weights": g12.uniform(0.1, 1.0, (m12, n12))}[mk]
+        par = dict(n_components=k12, alpha=float(g12.uniform(1.0, 3.0)), beta=float(g12.uniform(1.0, 3.0)),
+                   max_iter=int(g12.integers(3, 80)), tol=float(g12.choice([0.0, 1e-4, 1e-3])), random_state=int(g12.integers(0, 10000)),
+                   orientation=str(g12.choice(aliases)))
+        init = str(g12.choice(["seed", "both", "W", "H"], p=[0.5, 0.25, 0.125, 0.125]))
+        W0 = g12.uniform(0.05, 0.95, (m12, k12)) if init in ("both", "W") else None
+        H0 = g12.uniform(0.05, 0.95, (k12, n12)) if init in ("both", "H") else None
+        Xin = {"f64": X12, "int": X12.astype(np.int64), "bool": X12.astype(bool), "f32": X12.astype(np.float32),
+               "csr": sp.csr_matrix(X12)}[form]
+        mdl12 = NBMF(W_init=W0, H_init=H0, **par).fit(Xin, mask=M12)
+        pre = f"e{i}_"
+        est[pre + "params"] = np.array(json.dumps(dict(par, form=form, mask=mk, init=init)))
+        est[pre + "X"] = X12 if real else X12.astype(np.uint8)
+        est[pre + "mask"] = np.zeros(0) if M12 is None else (M12 if mk != "float01" else M12.astype(np.uint8))
+        est[pre + "W0"] = np.zeros(0) if W0 is None else W0
+        est[pre + "H0"] = np.zeros(0) if H0 is None else H0
+        est[pre + "W"], est[pre + "H"] = mdl12.W_, mdl12.components_
+        est[pre + "losses"], est[pre + "n_iter"] = np.array(mdl12.loss_curve_), np.array(mdl12.n_iter_)
+        est[pre + "orientation_after"] = np.array(mdl12.orientation)
+    np.savez_compressed(os.path.join(OUT, "estimator_random.npz"), **est)
 
     print("golden fixtures written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):

@@ -656,6 +656,32 @@ def test_round5_reference_fixtures(hip, golden, both_small_paths):
         assert (Hn[:, [5, 11]] == 1e-8).all()
 
 
+def test_estimator_random_reference_fixtures(hip, golden, both_small_paths):
+    """The reference's own outputs (tests/golden/estimator_random.npz, item 12 of oracle/make_golden.py) for twenty random
+    fits through its estimator: every orientation alias, the data handed over as the fixture says (float64 / int / bool /
+    float32 / CSR), masks of every kind, seeded and custom inits (on the simplex or not), stop rules that fire or not --
+    `NBMF(...)` here must give the same W_, components_, loss curve, n_iter_ and normalised `orientation`."""
+    import scipy.sparse as sp
+    from nbmf_mm_amd import NBMF
+    from test_oracle_golden import estimator_random_cases
+    n = 0
+    for c in estimator_random_cases(golden("estimator_random")):
+        par = dict(c["par"])
+        form, init, mkind = par.pop("form"), par.pop("init"), par.pop("mask")
+        X = {"f64": c["X"], "int": c["X"].astype(np.int64), "bool": c["X"].astype(bool), "f32": c["X"].astype(np.float32),
+             "csr": sp.csr_matrix(c["X"])}[form]
+        m = NBMF(W_init=c["W0"], H_init=c["H0"], **par).fit(X, mask=c["mask"])
+        tag = f"case {n}: {c['par']}"
+        assert m.n_iter_ == c["n_iter"], tag
+        assert m.orientation == c["orientation_after"], tag
+        np.testing.assert_allclose(m.loss_curve_, c["losses"], rtol=LOSS_RTOL, atol=0, err_msg=tag)
+        np.testing.assert_allclose(m.W_, c["W"], rtol=0, atol=FACTOR_ATOL, err_msg=tag)
+        np.testing.assert_allclose(m.components_, c["H"], rtol=0, atol=FACTOR_ATOL, err_msg=tag)
+        assert m.loss_ == m.loss_curve_[-1] == m.reconstruction_err_ and m.objective_history_ is m.loss_curve_
+        n += 1
+    assert n == 20
+
+
 _RAGGED_SCRIPT = r"""
 import json, os, sys
 import numpy as np

@@ -256,3 +256,43 @@ def test_round5_fixtures_real_valued_data_at_k16_k32_k64_and_columns_without_a_o
         np.testing.assert_array_equal(Wn, g["zc_W_new_" + tag])
         np.testing.assert_array_equal(Hn, g["zc_H_new_" + tag])
         assert (g["zc_H_new_" + tag][:, [5, 11]] == 1e-8).all()      # the clip's lower end, exactly
+
+
+ORIENTATION_ALIASES = {"beta-dir": "beta-dir", "dir-beta": "dir-beta", "Beta-Dir": "beta-dir", "Dir-Beta": "dir-beta",
+                       "Dir Beta": "dir-beta", "binary ICA": "beta-dir", "Binary ICA": "beta-dir", "bICA": "beta-dir",
+                       "Aspect Bernoulli": "dir-beta"}        # src/nbmf_mm/_base.py:126-136
+
+
+def estimator_random_cases(g):
+    """The twenty cases of tests/golden/estimator_random.npz (item 12 of oracle/make_golden.py) as dicts: parameters, the
+    inputs as float64 arrays (and how the reference was handed them), the reference's outputs."""
+    import json
+    for i in range(int(g["n_cases"])):
+        pre = f"e{i}_"
+        par = json.loads(str(g[pre + "params"]))
+        opt = lambda a: None if a.size == 0 else a          # noqa: E731
+        mask = opt(g[pre + "mask"])
+        yield dict(par=par, X=g[pre + "X"].astype(np.float64), mask=None if mask is None else mask.astype(np.float64) if par["mask"] != "bool" else mask,
+                   W0=opt(g[pre + "W0"]), H0=opt(g[pre + "H0"]), W=g[pre + "W"], H=g[pre + "H"], losses=g[pre + "losses"],
+                   n_iter=int(g[pre + "n_iter"]), orientation_after=str(g[pre + "orientation_after"]))
+
+
+def test_estimator_random_fixtures_through_the_restatement(golden):
+    """Item 12: twenty random fits of the REFERENCE's estimator -- every orientation alias, data handed over as float64 /
+    int / bool / float32 / CSR, masks of every kind, seeded and custom inits, stop rules that fire or not.  The estimator adds
+    nothing to the solver but input conversion and the alias table (_base.py:79-121), so the restated solver on the converted
+    inputs must meet W_, components_, the loss curve and n_iter_ bitwise."""
+    n = 0
+    for c in estimator_random_cases(golden("estimator_random")):
+        par = c["par"]
+        assert c["orientation_after"] == ORIENTATION_ALIASES[par["orientation"]]      # fit stores the normalised form (:95)
+        mask = None if c["mask"] is None else np.asarray(c["mask"])
+        W, H, losses, _, n_iter = orc.solve(c["X"], par["n_components"], max_iter=par["max_iter"], tol=par["tol"], alpha=par["alpha"],
+                                            beta=par["beta"], W_init=c["W0"], H_init=c["H0"], mask=mask,
+                                            random_state=par["random_state"], orientation=c["orientation_after"])
+        assert n_iter == c["n_iter"], par
+        np.testing.assert_array_equal(np.array(losses), c["losses"], err_msg=str(par))
+        np.testing.assert_array_equal(W, c["W"], err_msg=str(par))
+        np.testing.assert_array_equal(H, c["H"], err_msg=str(par))
+        n += 1
+    assert n == 20
