@@ -151,6 +151,20 @@ def test_estimators_dropped_without_ceremony(hip):
     gc.collect()
     after = _free_bytes(hip)
     assert abs(base - after) <= 16 << 20, f"device memory moved by {(base - after) / 2**20:.1f} MiB over 20 estimators"
+    # ... and so a fitted estimator is plain data: it survives pickling and sklearn's clone protocol (joblib ships estimators
+    # to workers this way), and the copy evaluates as the original does
+    import pickle
+    from sklearn.base import clone
+    est = NBMF(n_components=8, max_iter=20, random_state=3).fit(X)
+    copy = pickle.loads(pickle.dumps(est))
+    np.testing.assert_array_equal(copy.components_, est.components_)
+    np.random.seed(5)
+    a = est.transform(X[:40])
+    np.random.seed(5)
+    b = copy.transform(X[:40])
+    np.testing.assert_array_equal(a, b)
+    fresh = clone(est)
+    assert not hasattr(fresh, "components_") and fresh.get_params() == est.get_params()
 
 
 _SHARDED_SCRIPT = r"""
