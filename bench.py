@@ -467,6 +467,7 @@ def run_rank(args, rank, local_rank, world):
             "metric": "MM-iterations/sec", "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic (generated on device)" if args.device_data else "synthetic",
+            "library": {"abi": _hip.load().nbmf_abi_version(), "source_hash": _hip.source_hash(), "tree_source_hash": _hip.tree_source_hash()},
             "final_nll_per_entry": float(losses[-1]), "replicas_identical": replicas_identical,
             "loss_monotone": bool(all(losses[i] <= losses[i - 1] + 1e-12 for i in range(1, len(losses)))),
             "normalize_value": by_proj["normalize"], "duchi_value": by_proj["duchi"],

@@ -52,6 +52,10 @@ typedef struct nbmf_ctx nbmf_ctx;
 
 /* library / device ------------------------------------------------------------------------ */
 int nbmf_abi_version(void);
+/* First 12 hex digits of the SHA-256 over the sources this binary was compiled from (csrc/nbmf_hip.hip, the .inc files beside it sorted
+ * by name, include/nbmf_hip.h), stamped by csrc/Makefile; "unstamped" for a build that did not go through it.  bench.py
+ * prints it on its line and tools/refresh_profiles.sh refuses a profile whose library is not the tree's. */
+const char* nbmf_source_hash(void);
 const char* nbmf_last_error(void);
 int nbmf_device_count(int* count);
 
@@ -249,9 +253,23 @@ int nbmf_set_exchange_panels(nbmf_ctx* ctx, int panels);
  * cannot work on this machine costs seconds, not a timeout per exchange. */
 int nbmf_set_peer_timeout_ms(nbmf_ctx* ctx, double ms);
 
+/* Cancel from another thread (the ONLY call that may be made on a context while its owner thread is inside one): sticky;
+ * the owner's nbmf_run returns NBMF_ERR_STATE at its next iteration boundary, and what it has already enqueued is cut
+ * short on the device by the run's own stop flag (the word the kernels honour after convergence, _solver.py:169-175).
+ * The reference's loop is interrupted by KeyboardInterrupt between NumPy calls; this is what a host thread that joins
+ * rank threads (NBMF(n_gpus=N)) uses for the same purpose.  The context can only be destroyed afterwards. */
+int nbmf_cancel(nbmf_ctx* ctx);
+
 /* Drop the attached communicator (RCCL, host or peer): the context is a single-GPU context over its own
  * shard again and another nbmf_comm_init* may follow.  Collective in effect: every rank must do the same. */
 int nbmf_comm_detach(nbmf_ctx* ctx);
+
+/* What the attached transport itself reports (no reference counterpart: diagnostics of the sharded loop that replaces
+ * _solver.py:143-175 on several GPUs).  kind: 0 none, 1 RCCL, 2 peer, 3 host.  nranks_seen: RCCL -- ncclCommCount of the
+ * communicator (-1 if this librccl has no such symbol); peer -- arenas mapped, this rank's included; host -- the nranks
+ * it was given.  remote: RCCL -- ncclCommCuDevice (the device RCCL bound the communicator to, -1 if unknown); peer / host
+ * -- how many of the other ranks' buffers are reached from outside this context.  Any pointer may be NULL. */
+int nbmf_comm_info(nbmf_ctx* ctx, int* kind, int* nranks_seen, int* remote);
 
 /* Measurement: HIP-event timing of the two fused pass kernels on the context's stream.  enable: 0 = off, 1 = every
  * sweep, n > 1 = the sweeps of every n-th iteration of a run (a timed dispatch costs ~2.5 us: at sub-millisecond

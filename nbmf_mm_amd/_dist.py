@@ -217,7 +217,8 @@ def fit_row_sharded(Y_local, M_global, r0, n_components, group, max_iter=500, to
 
 def fit_sharded(V_local, global_shape, offset, n_components, group, orientation="beta-dir", shard="rows",
                 max_iter=500, tol=1e-5, alpha=1.2, beta=1.2, W_init=None, H_init=None, mask_local=None,
-                random_state=None, eps=1e-8, projection="normalize", device=0, transport="auto", progress=None):
+                random_state=None, eps=1e-8, projection="normalize", device=0, transport="auto", progress=None,
+                _register=None):
     """Sharded fit in the user's orientation, V split over the ranks by ``shard`` = "rows"
     (``V_local = V[offset:offset+len, :]``) or "cols" (``V_local = V[:, offset:offset+len]``).
 
@@ -254,6 +255,8 @@ def fit_sharded(V_local, global_shape, offset, n_components, group, orientation=
     else:
         ctx_shape, W0, H0, axis = (m_int, length), Wi, Hi[:, sl], 1
     with _hip.Context(ctx_shape[0], ctx_shape[1], K, device=device) as ctx:
+        if _register is not None:
+            _register(ctx)                 # (fit_in_process: the thread that joins the ranks may have to cancel this context)
         ctx.set_hyper(alpha, beta, eps, _projection_code(projection))
         upload_any(ctx, V_local, mask_local, transposed=transposed)    # the pack applies the transpose
         ctx.set_factors(np.ascontiguousarray(W0), np.ascontiguousarray(H0))
@@ -339,8 +342,16 @@ def fit_in_process(V, n_components, n_gpus, devices=None, orientation="beta-dir"
             if it % 10 == 0:
                 print(f"Iter {it:4d}: Loss = {loss:.6f}", flush=True)
 
+    contexts, interrupted = [None] * n_gpus, threading.Event()
+
     def body(r):
         live = {"progress": _report} if (verbose > 0 and r == 0) else {}
+        if _rank_fit is None:
+            def register(ctx, r=r):
+                contexts[r] = ctx
+                if interrupted.is_set():      # the caller was interrupted while this rank was still setting up
+                    ctx.cancel()
+            live["_register"] = register
         try:
             with groups[r] as g:                                          # (whatever fails in here aborts the group: nobody waits for this rank)
                 r0, r1 = shard_bounds(M, n_gpus, r)
@@ -351,13 +362,38 @@ def fit_in_process(V, n_components, n_gpus, devices=None, orientation="beta-dir"
         except BaseException as e:                                       # noqa: B902 (re-raised in the caller's thread)
             errors[r] = e
 
-    # (daemon threads: a Ctrl-C in the caller's join() must be able to end the process even while a rank sits in a HIP call)
     threads = [threading.Thread(target=body, args=(r,), name=f"nbmf-rank-{r}", daemon=True) for r in range(n_gpus)]
     for t in threads:
         t.start()
-    for t in threads:
-        t.join()
-    first = [e for e in errors if e is not None and not isinstance(e, ConnectionError)] or [e for e in errors if e is not None]
+    try:
+        for t in threads:
+            while t.is_alive():
+                t.join(0.2)                  # (a bounded wait: KeyboardInterrupt is delivered between the waits)
+    except BaseException:
+        # Ctrl-C (or anything else) in the caller: the ranks must not go on sweeping and exchanging behind its back.  Their
+        # group is aborted (whoever sits in a collective leaves it), their contexts are cancelled (the runs end at the next
+        # iteration; what is enqueued is cut short on the device, the exchange kernels included), and they are given a
+        # bounded time to unwind -- closing their contexts, which frees the device memory and the hardware queues -- before
+        # the interrupt goes on to the caller.  daemon=True is only the last resort for a rank stuck inside a device call.
+        import time
+        interrupted.set()
+        for g in groups:
+            g.abort()
+        for ctx in contexts:
+            if ctx is not None:
+                try:
+                    ctx.cancel()
+                except Exception:            # noqa: BLE001  (a context that is already closed)
+                    pass
+        deadline = time.monotonic() + float(os.environ.get("NBMF_INTERRUPT_JOIN_S", "30"))
+        for t in threads:
+            t.join(max(0.0, deadline - time.monotonic()))
+        raise
+    # which error to show: a rank's own failure first; among the ConnectionErrors that followed from it (or from a rank
+    # that never arrived) the one that NAMES the missing ranks before the generic "another rank has failed"
+    first = ([e for e in errors if e is not None and not isinstance(e, ConnectionError)]
+             or [e for e in errors if e is not None and "did not reach" in str(e)]
+             or [e for e in errors if e is not None])
     if first:
         raise first[0]
     losses, n_iter = results[0][2], results[0][3]

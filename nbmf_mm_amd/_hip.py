@@ -36,7 +36,7 @@ SYMBOLS = [
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
     "nbmf_set_progress", "nbmf_device_synchronize", "nbmf_small_stats", "nbmf_generate_slice", "nbmf_set_storage",
     "nbmf_set_exchange_panels", "nbmf_set_peer_timeout_ms", "nbmf_run_batch", "nbmf_batch_stats", "nbmf_sweep_info",
-    "nbmf_upload_v", "nbmf_selftest_mfma_peak", "nbmf_engine_stats",
+    "nbmf_upload_v", "nbmf_selftest_mfma_peak", "nbmf_engine_stats", "nbmf_source_hash", "nbmf_comm_info", "nbmf_cancel",
 ]
 DATA_F64, DATA_U8, DATA_F32 = 0, 1, 2
 
@@ -83,13 +83,16 @@ def _autobuild(path):
             raise NBMFHipError(f"building {path} failed:\n{r.stdout[-2000:]}")
 
 
-_HW_QUEUES_AT_LOAD = None
+# GPU_MAX_HW_QUEUES is read by the HIP runtime at ITS first call, whoever makes it -- another HIP user of the process
+# (PyTorch, say) may do so before this library is ever loaded.  The earliest moment this package can observe the variable
+# is its own import: that value is recorded, and it is an UPPER bound on what the runtime has only if nothing in the
+# process started HIP before with a smaller one (set it before ANY HIP user of the process starts).
+_HW_QUEUES_AT_LOAD = os.environ.get("GPU_MAX_HW_QUEUES")
 
 
 def hw_queues_at_load():
-    """GPU_MAX_HW_QUEUES as it stood when the library (and with it, at the latest, the HIP runtime) was loaded; the
-    runtime's default (4) if it was not set."""
-    load()
+    """GPU_MAX_HW_QUEUES as it stood when this package was imported (no later than the library's load and hence, unless
+    another HIP user of the process was there first, than the runtime's start); the runtime's default (4) if unset."""
     try:
         return int(_HW_QUEUES_AT_LOAD) if _HW_QUEUES_AT_LOAD is not None else 4
     except ValueError:
@@ -109,11 +112,6 @@ def load():
             f"{path} not found: build it with `make -C nbmf_mm_amd/csrc` (needs hipcc); "
             "nbmf_mm_amd has no CPU fallback")
     lib = ctypes.CDLL(path)
-    # The HIP runtime reads GPU_MAX_HW_QUEUES when it starts, which is no later than the first call into this library:
-    # what the variable says NOW is what the process has (a value set afterwards changes nothing) -- _dist.fit_in_process
-    # checks this record, not the environment of the moment.
-    global _HW_QUEUES_AT_LOAD
-    _HW_QUEUES_AT_LOAD = os.environ.get("GPU_MAX_HW_QUEUES")
     if "NBMF_HIP_LIBRARY" in os.environ:
         # an explicitly named build (A/B measurements against an older library): entry points it lacks raise when called
         class _Missing:
@@ -127,6 +125,9 @@ def load():
                 setattr(lib, name, _Missing(name))
     dp = POINTER(c_double)
     lib.nbmf_abi_version.restype = c_int
+    lib.nbmf_source_hash.restype = c_char_p
+    lib.nbmf_cancel.argtypes = [c_void_p]
+    lib.nbmf_comm_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     lib.nbmf_last_error.restype = c_char_p
     lib.nbmf_device_count.argtypes = [POINTER(c_int)]
     lib.nbmf_create.argtypes = [c_int64, c_int64, c_int, c_int, POINTER(c_void_p)]
@@ -168,7 +169,7 @@ def load():
     lib.nbmf_small_stats.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.nbmf_selftest_unary.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p]
     for name in SYMBOLS:
-        if name != "nbmf_last_error":
+        if name not in ("nbmf_last_error", "nbmf_source_hash"):
             getattr(lib, name).restype = c_int
     _lib = lib
     return lib
@@ -183,6 +184,31 @@ def _check(rc):
     if rc == NBMF_ERR_ARG:
         raise ValueError(msg)
     raise NBMFHipError(msg)
+
+
+def source_hash() -> str:
+    """The content hash of the sources the loaded library was compiled from (``nbmf_source_hash``)."""
+    try:
+        return load().nbmf_source_hash().decode()
+    except NBMFHipError:                    # an older build named by NBMF_HIP_LIBRARY
+        return "unknown"
+
+
+def tree_source_hash():
+    """The same hash computed from the sources next to this file (csrc/Makefile's recipe; tools/src_hash.sh), or None
+    where the package was installed without them."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    files = ([os.path.join(csrc, "nbmf_hip.hip")] + sorted(glob.glob(os.path.join(csrc, "*.inc"))) +
+             [os.path.join(_HERE, "..", "include", "nbmf_hip.h")])
+    if not all(os.path.exists(f) for f in files):
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
 
 
 def device_count() -> int:
@@ -417,6 +443,22 @@ class Context:
         """Drop the attached communicator; every rank must do the same."""
         _check(self._lib.nbmf_comm_detach(self._h))
         self._host_cb = None
+
+    def cancel(self):
+        """From ANOTHER thread: make the owner's ``run`` return (NBMFHipError "cancelled") at its next iteration boundary and
+        cut short what it has enqueued (``nbmf_cancel``).  Sticky: the context can only be closed afterwards."""
+        if self._h:
+            _check(self._lib.nbmf_cancel(self._h))
+
+    COMM_KINDS = {0: "none", 1: "rccl", 2: "peer", 3: "host"}
+
+    def comm_info(self):
+        """What the attached transport itself reports (``nbmf_comm_info``): ``{"kind", "nranks_seen", "remote"}`` --
+        RCCL: ncclCommCount / ncclCommCuDevice of the communicator (-1 where librccl lacks the symbol); peer: arenas
+        mapped (own included) / how many of them belong to other ranks; host: as given."""
+        k, n, r = c_int(0), c_int(0), c_int(0)
+        _check(self._lib.nbmf_comm_info(self._h, byref(k), byref(n), byref(r)))
+        return {"kind": self.COMM_KINDS.get(k.value, str(k.value)), "nranks_seen": n.value, "remote": r.value}
 
     def timing_enable(self, on=True):
         """on: False / True, or an int n > 1 for the sweeps of every n-th iteration only."""

@@ -276,6 +276,7 @@ class LocalGroup:
             self.slots = [None] * world
             self.timeout = timeout
             self.arrivals = [0] * world        # how many barrier waits each rank has entered (diagnosis of a timeout)
+            self.timed_out = None              # (missing ranks, timeout) once a wait has run out: what every later failure reports
 
     def __init__(self, shared, rank, world):
         self._s, self.rank, self.world = shared, rank, world
@@ -300,8 +301,13 @@ class LocalGroup:
             # broken by a failed rank's abort(), or by a timeout -- this rank's own or, once that has broken the barrier,
             # somebody else's: whoever has not entered this wait is the one everybody was waiting for
             missing = [r for r, n in enumerate(s.arrivals) if n < mine]
-            if missing and s.timeout is not None and time.monotonic() - t0 >= 0.9 * s.timeout:
-                raise ConnectionError(f"rank(s) {missing} of this process did not reach a collective within {s.timeout:g} s "
+            if missing and s.timeout is not None and time.monotonic() - t0 >= 0.9 * s.timeout and s.timed_out is None:
+                s.timed_out = (missing, s.timeout)
+            # the diagnosis belongs to the group, not to whoever happened to wait longest: a rank that enters a collective
+            # AFTER the barrier broke (the late one itself, say) reports the same ranks and the same bound
+            if s.timed_out is not None:
+                gone, bound = s.timed_out
+                raise ConnectionError(f"rank(s) {gone} of this process did not reach a collective within {bound:g} s "
                                       f"(stuck in a device call?)") from None
             raise ConnectionError("another rank of this process has failed") from None
 

@@ -411,6 +411,7 @@ struct nbmf_ctx {
   nbmf_progress_fn progress = nullptr;
   void* progress_user = nullptr;
   int progress_every = 0;
+  std::atomic<int> cancelled{0};   // nbmf_cancel (any thread): sticky; runs return NBMF_ERR_STATE at the next iteration boundary
   // timing
   bool timing = false;
   int timing_stride = 1;   // events on the sweeps of every timing_stride-th iteration of a run (nbmf_timing_enable)
@@ -587,6 +588,8 @@ struct Rccl {
   int (*CommInitRank)(void**, int, /*ncclUniqueId by value*/ Uid, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;      // optional: how many ranks the communicator itself says it joins (nbmf_comm_info)
+  int (*CommCuDevice)(void*, int*) = nullptr;   // optional: the device it is bound to
   const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -626,6 +629,8 @@ int load_rccl() {
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
   g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  g_rccl.CommCount = (int (*)(void*, int*))dlsym(lib, "ncclCommCount");
+  g_rccl.CommCuDevice = (int (*)(void*, int*))dlsym(lib, "ncclCommCuDevice");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
     return fail(NBMF_ERR_COMM, "librccl is missing expected symbols");
   g_rccl.lib = lib;
@@ -773,7 +778,7 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
   dim3 grid(a_.Cb / WG_WAVES, chunks);
   constexpr int lds_bytes = pass_lds_bytes(KB, DATA, MODE);
   if (lds_bytes > 65536) {
-    hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH, TINY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH, TINY, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
   }
   PassArgs a = a_;
@@ -2414,7 +2419,14 @@ int set_device(nbmf_ctx* c) {
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-int nbmf_abi_version(void) { return 3; }   // 2: NBMF_PEER_HANDLE_BYTES 128 -> 192, nbmf_generate_slice, nbmf_set_storage; 3: nbmf_upload_v (uint8 / bool data), nbmf_selftest_mfma_peak, nbmf_engine_stats
+int nbmf_abi_version(void) { return 4; }   // 2: NBMF_PEER_HANDLE_BYTES 128 -> 192, nbmf_generate_slice, nbmf_set_storage; 3: nbmf_upload_v (uint8 / bool data), nbmf_selftest_mfma_peak, nbmf_engine_stats; 4: nbmf_source_hash, nbmf_comm_info, nbmf_cancel
+// The sources this binary was compiled from: first 12 hex digits of the SHA-256 over nbmf_hip.hip, the *.inc files (sorted
+// by name) and include/nbmf_hip.h, put in by the Makefile (tools/src_hash.sh prints the same for the tree).  A profile or a
+// bench line that quotes it can be tied to a commit; a library built by hand without the Makefile says "unstamped".
+#ifndef NBMF_SRC_HASH
+#define NBMF_SRC_HASH "unstamped"
+#endif
+const char* nbmf_source_hash(void) { return NBMF_SRC_HASH; }
 
 const char* nbmf_last_error(void) { return g_err.c_str(); }
 
@@ -2911,6 +2923,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   if (int rc = ready(c)) return rc;
   if (max_iter < 1) return fail(NBMF_ERR_ARG, "max_iter must be >= 1");
   if (!losses || !n_iter) return fail(NBMF_ERR_ARG, "null output");
+  if (c->cancelled.load(std::memory_order_relaxed)) return fail(NBMF_ERR_STATE, "cancelled (nbmf_cancel)");
   if (int rc = set_device(c)) return rc;
   if (int rc = ensure_losses(c, max_iter)) return rc;
   HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
@@ -2969,6 +2982,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   while (it < max_iter && !host_done) {
     const int end = std::min(max_iter, it + batch);
     for (; it < end; ++it) {
+      if (c->cancelled.load(std::memory_order_relaxed)) return fail(NBMF_ERR_STATE, "cancelled (nbmf_cancel)");
       c->timing_it = it;
       if (use_graph) {
         HIPCHK(hipGraphLaunch(gexec, c->stream));
@@ -3017,6 +3031,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
     HIPCHK(hipStreamSynchronize(c->stream));
     return fail(NBMF_ERR_STATE, "internal: a sweep's loss assembly timed out waiting for its workgroups' partials");
   }
+  if (c->cancelled.load(std::memory_order_relaxed)) return fail(NBMF_ERR_STATE, "cancelled (nbmf_cancel)");
   const int nit = fl[1];
   if (nit < 1 || nit > max_iter) return fail(NBMF_ERR_STATE, "internal: device reported n_iter=%d", nit);
   if (int rc = report(nit)) return rc;
@@ -3247,6 +3262,26 @@ int nbmf_comm_init_host(nbmf_ctx* c, nbmf_host_allreduce_fn fn, void* user, int 
   return comm_finish_init(c, nranks, rank, shard_axis);
 }
 
+// Cooperative cancellation from ANOTHER thread (the only entry point that may be called on a context while its owner is
+// inside a call): the flag is sticky; what is already enqueued is cut short on the device by raising the run's own stop
+// flag -- the word every kernel of an iteration (the exchange kernels included) looks at before it does anything, as after
+// convergence -- through a stream of its own.  The owner's nbmf_run then returns NBMF_ERR_STATE ("cancelled").
+int nbmf_cancel(nbmf_ctx* c) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  c->cancelled.store(1, std::memory_order_relaxed);
+  int* flags = c->flags;
+  if (!flags) return NBMF_OK;
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = nullptr;
+  HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  static const int one = 1;
+  hipError_t e = hipMemcpyAsync(flags, &one, sizeof(int), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipStreamDestroy(st);
+  if (e != hipSuccess) return fail(NBMF_ERR_HIP, "nbmf_cancel: %s", hipGetErrorString(e));
+  return NBMF_OK;
+}
+
 int nbmf_set_peer_timeout_ms(nbmf_ctx* c, double ms) {
   if (!c) return fail(NBMF_ERR_ARG, "null context");
   if (!(ms >= 0.0)) return fail(NBMF_ERR_ARG, "timeout must be >= 0 ms");
@@ -3267,6 +3302,37 @@ int nbmf_comm_detach(nbmf_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->stream2) HIPCHK(hipStreamSynchronize(c->stream2));
   comm_release(c, /*recount=*/true);
+  return NBMF_OK;
+}
+
+// What the attached transport ITSELF says about the job (as opposed to what the caller told it): for RCCL the
+// communicator's own rank count and device (ncclCommCount / ncclCommCuDevice: -1 where this librccl lacks them), for the
+// peer transport the number of arenas it has mapped (its own included) and how many of those it reaches over IPC or peer
+// access -- i.e. outside this context's own device memory.
+int nbmf_comm_info(nbmf_ctx* c, int* kind, int* nranks_seen, int* remote) {
+  if (!c) return fail(NBMF_ERR_ARG, "null context");
+  int k = 0, n = 0, rem = 0;
+  if (c->comm) {
+    k = 1;
+    n = -1;
+    rem = -1;
+    if (g_rccl.CommCount) NCCLCHK(g_rccl.CommCount(c->comm, &n));
+    if (g_rccl.CommCuDevice) NCCLCHK(g_rccl.CommCuDevice(c->comm, &rem));
+  } else if (c->peer) {
+    k = 2;
+    for (int j = 0; j < c->pv.nranks; ++j)
+      if (c->pv.arena[j] && c->pv.flag[j]) {
+        ++n;
+        if (j != c->pv.rank) ++rem;
+      }
+  } else if (c->host_reduce) {
+    k = 3;
+    n = c->nranks;
+    rem = c->nranks - 1;
+  }
+  if (kind) *kind = k;
+  if (nranks_seen) *nranks_seen = n;
+  if (remote) *remote = rem;
   return NBMF_OK;
 }
 

@@ -4,7 +4,8 @@
 Run in the build container only:  python oracle/make_golden.py
 It imports ``nbmf_mm`` from /root/reference/src (never copied into this repo) and stores
 inputs (when not regenerable from a seed) and the reference's outputs as small fixtures.
-The case list is SURVEY.md §8c items 1-9, plus (item 10, round 4) storage paths and input kinds beyond them and (item 11, round 5) real-valued data at K = 16 / 32 / 64 and columns without a one under a flat prior, and (item 12) twenty random fits through the estimator.  The GPU box never runs this script.
+The case list is SURVEY.md §8c items 1-9, plus (item 10, round 4) storage paths and input kinds beyond them and (item 11, round 5) real-valued data at K = 16 / 32 / 64 and columns without a one under a flat prior, and (item 12) twenty random fits through the estimator, and (item 13, round 6) the held-out perplexity of the reference's experiment driver.  The GPU box never runs this script.
+`python oracle/make_golden.py heldout` writes item 13's file only.
 """
 import os
 import sys
@@ -13,6 +14,47 @@ import numpy as np
 
 REF_SRC = "/root/reference/src"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def reference_compute_perplexity():
+    """`compute_perplexity` of the reference's experiment script (examples/reproduce_magron2022.py:40-47) WITHOUT importing
+    the script (its module level needs pyreadr / pandas and creates directories): the one function definition is taken
+    out of the parsed source and compiled here, in the build container, with NumPy as its only global.  Nothing of the
+    text is stored anywhere."""
+    import ast
+    path = "/root/reference/examples/reproduce_magron2022.py"
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = [node for node in tree.body if isinstance(node, ast.FunctionDef) and node.name == "compute_perplexity"]
+    if len(fn) != 1:
+        sys.exit("compute_perplexity not found in " + path)
+    ns = {"np": np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    return ns["compute_perplexity"]
+
+
+def heldout():
+    """13. held-out perplexity (round 6): the reference's estimator fitted on the training entries of a seeded 40 x 70
+    problem, then the reference driver's own compute_perplexity of W_ @ components_ on the validation and the test
+    entries (strict masks), on a real-valued weight mask, and with no mask at all."""
+    sys.path.insert(0, REF_SRC)
+    from nbmf_mm import NBMF
+    ref_perp = reference_compute_perplexity()
+    g = np.random.default_rng(1313)
+    Y = (g.random((40, 70)) < 0.3).astype(np.float64)
+    u = g.random((40, 70))
+    train, val, test = u < 0.7, (u >= 0.7) & (u < 0.85), u >= 0.85
+    weights = g.uniform(0.0, 1.0, (40, 70)) * (u >= 0.7)
+    mdl = NBMF(n_components=5, orientation="beta-dir", alpha=1.2, beta=1.2, max_iter=60, tol=1e-5, random_state=12345).fit(Y, mask=train)
+    Y_hat = mdl.W_ @ mdl.components_
+    out = dict(Y=Y.astype(np.uint8), train=train, val=val, test=test, weights=weights, W=mdl.W_, H=mdl.components_,
+               losses=np.array(mdl.loss_curve_), n_iter=np.array(mdl.n_iter_),
+               perp_val=np.array(ref_perp(Y, Y_hat, val)), perp_test=np.array(ref_perp(Y, Y_hat, test)),
+               perp_val_float=np.array(ref_perp(Y, Y_hat, val.astype(np.float64))),
+               perp_weights=np.array(ref_perp(Y, Y_hat, weights)), perp_nomask=np.array(ref_perp(Y, Y_hat)),
+               perp_eps=np.array(ref_perp(Y, Y_hat, test, eps=1e-6)))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "heldout.npz"), **out)
+    print("heldout.npz:", {k: float(v) for k, v in out.items() if k.startswith("perp")}, "n_iter", int(out["n_iter"]))
 
 
 def main():
@@ -250,10 +292,17 @@ def main():
         est[pre + "orientation_after"] = np.array(mdl12.orientation)
     np.savez_compressed(os.path.join(OUT, "estimator_random.npz"), **est)
 
+    heldout()
+
     print("golden fixtures written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print("  %-20s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["heldout"]:
+        if not os.path.isdir(REF_SRC):
+            sys.exit("reference not present: goldens can only be regenerated in the build container")
+        heldout()
+    else:
+        main()

@@ -13,10 +13,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nbmf_mm_amd import _hip  # noqa: E402
 
 lib = _hip.load()
-assert lib.nbmf_abi_version() == 3
+assert lib.nbmf_abi_version() == 4
 results = {}
 for name in _hip.SYMBOLS:
-    if name in ("nbmf_abi_version", "nbmf_last_error"):
+    if name in ("nbmf_abi_version", "nbmf_last_error", "nbmf_source_hash"):
         continue
     fn = getattr(lib, name)
     args = []

@@ -26,7 +26,7 @@ int main(void) {
   int i, j, k, n_iter = 0, flags = 0, ndev = 0;
   double n_obs = 0, loss_now = 0, ll = 0;
   nbmf_ctx* ctx = NULL;
-  if (nbmf_abi_version() != 3) return 2;
+  if (nbmf_abi_version() != 4) return 2;
   if (nbmf_device_count(&ndev) != NBMF_OK || ndev < 1) { fprintf(stderr, "no GPU: %s\n", nbmf_last_error()); return 3; }
   for (i = 0; i < M * N; ++i) { Y[i] = urand() < 0.3 ? 1.0 : 0.0; mask[i] = urand() < 0.9 ? 1.0 : 0.0; }
   for (i = 0; i < M; ++i) {           /* W: k x m, columns on the simplex (_solver.py:132-136) */

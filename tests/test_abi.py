@@ -24,7 +24,22 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_hip.SYMBOLS) == declared, "python binding list and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"libnbmf_hip.so does not export {name}"
-    assert lib.nbmf_abi_version() == 3
+    assert lib.nbmf_abi_version() == 4
+
+
+def test_library_is_the_build_of_these_sources():
+    """The library carries the content hash of the sources it was compiled from (csrc/Makefile -> nbmf_source_hash): it
+    must be the hash of the tree's sources -- on the GPU box too, where the .so travels with the snapshot: a stale binary
+    cannot stand in for the sources it is shipped with.  tools/src_hash.sh prints the same."""
+    import subprocess
+    from nbmf_mm_amd import _hip
+    if "NBMF_HIP_LIBRARY" in os.environ:
+        pytest.skip("an explicitly named build")
+    want = _hip.tree_source_hash()
+    assert want is not None and re.fullmatch(r"[0-9a-f]{12}", want)
+    assert _hip.source_hash() == want, "libnbmf_hip.so was not built from the sources in the tree: run make -C nbmf_mm_amd/csrc"
+    sh = subprocess.run(["bash", os.path.join(ROOT, "tools", "src_hash.sh")], capture_output=True, text=True)
+    assert sh.stdout.strip() == want
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -685,3 +685,72 @@ def test_local_group_names_the_rank_that_never_arrives():
         t.join(20)
     gate.set()
     assert errs[0] and errs[1] and all("rank(s) [2]" in e and "0.5 s" in e for e in errs[:2]), errs
+
+
+def test_fit_in_process_interrupted_caller_ends_every_rank():
+    """Ctrl-C while the caller joins the rank threads: the ranks' group is aborted, the threads end within the bound and
+    the interrupt goes on to the caller -- nothing keeps sweeping behind its back (with real contexts they are cancelled
+    as well: tests/test_gpu_lifecycle.py)."""
+    import _thread
+    import threading
+    import time
+    from nbmf_mm_amd import _dist
+    V = (np.random.default_rng(3).random((40, 30)) < 0.3).astype(np.float64)
+    started = threading.Barrier(4)
+
+    def endless(V_local, global_shape, offset, K, group, **kw):
+        started.wait(10)
+        while True:                                   # "sweeping": a collective per iteration, for ever
+            group.barrier()
+            time.sleep(0.005)
+
+    def interrupt():
+        started.wait(10)
+        time.sleep(0.3)
+        _thread.interrupt_main()
+    threading.Thread(target=interrupt, daemon=True).start()
+    t0 = time.monotonic()
+    with pytest.raises(KeyboardInterrupt):
+        _dist.fit_in_process(V, 3, 3, devices=[0] * 3, max_iter=5, tol=0, _rank_fit=endless)
+    assert time.monotonic() - t0 < 10
+    assert not [t for t in threading.enumerate() if t.name.startswith("nbmf-rank-")]
+
+
+def test_local_group_late_rank_gets_the_named_diagnosis_too():
+    """The rank everybody waited for arrives AFTER the barrier broke: it reports the same missing ranks and bound as the
+    ranks that timed out, and fit_in_process shows that error rather than a generic one."""
+    import threading
+    from nbmf_mm_amd import _dist, _rendezvous
+    groups = _rendezvous.LocalGroup.make(3, timeout=0.4)
+    errs, gate = [None] * 3, threading.Event()
+
+    def body(r):
+        try:
+            if r == 0:
+                gate.wait(10)                        # the late one (rank 0: the error fit_in_process used to show)
+            groups[r].barrier()
+        except ConnectionError as e:
+            errs[r] = str(e)
+            if r != 0:
+                gate.set()
+    ts = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(20)
+    assert all(e and "rank(s) [0]" in e and "0.4 s" in e for e in errs), errs
+    # through fit_in_process: rank 0 is late (stuck), the others time out; whichever error is raised names rank 0
+    V = (np.random.default_rng(3).random((40, 30)) < 0.3).astype(np.float64)
+    import os
+    os.environ["NBMF_LOCAL_GROUP_TIMEOUT_S"] = "0.4"
+    try:
+        def late(V_local, global_shape, offset, K, group, **kw):
+            if group.rank == 0:
+                import time
+                time.sleep(1.0)
+            group.barrier()
+            raise AssertionError("unreachable")
+        with pytest.raises(ConnectionError, match=r"rank\(s\) \[0\]"):
+            _dist.fit_in_process(V, 3, 3, devices=[0] * 3, max_iter=5, tol=0, _rank_fit=late)
+    finally:
+        del os.environ["NBMF_LOCAL_GROUP_TIMEOUT_S"]

@@ -275,3 +275,71 @@ def test_a_context_used_again_is_a_fresh_one(hip):
                 ctx.w_only_steps(3)                                      # an evaluation-time call between two fits
                 ctx.loglik_strict()
         assert fresh[0] == fresh[4]
+
+
+def test_cancel_from_another_thread_ends_a_run(hip):
+    """``nbmf_cancel``: a run of 10**6 iterations with tol = 0 is enqueued far ahead of the device; cancelled from another
+    thread it comes back within seconds with the library's "cancelled" error (the enqueue loop stops and the run's own stop
+    flag cuts short what is queued), the context stays cancelled, closes cleanly, and the next fit on the device is the
+    usual one.  (With tol > 0 the loop is left at the next batch boundary; both are covered.)"""
+    import threading
+    import time
+    g = np.random.default_rng(11)
+    V = (g.random((2048, 1536)) < 0.3).astype(np.float64)
+    want = _one_fit(hip, V, None, 64, 4)
+    for tol in (0.0, 1e-300):
+        ctx = hip.Context(2048, 1536, 64)
+        try:
+            ctx.upload(V)
+            W0 = g.random((64, 2048))
+            ctx.set_factors(W0 / W0.sum(axis=0, keepdims=True), g.uniform(0.1, 0.9, (64, 1536)))
+            threading.Timer(0.5, ctx.cancel).start()
+            t0 = time.monotonic()
+            with pytest.raises(hip.NBMFHipError, match="cancelled"):
+                ctx.run(10 ** 6, tol)
+            assert time.monotonic() - t0 < 60.0
+            with pytest.raises(hip.NBMFHipError, match="cancelled"):
+                ctx.run(3, 0.0)
+        finally:
+            ctx.close()
+    assert _one_fit(hip, V, None, 64, 4) == want
+
+
+_INTERRUPT_SCRIPT = r"""
+import json, sys, threading, time, _thread
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from nbmf_mm_amd import NBMF
+g = np.random.default_rng(4)
+X = (g.random((4100, 2048)) < 0.3).astype(np.float64)
+def interrupt():
+    time.sleep(3.0)
+    _thread.interrupt_main()
+threading.Thread(target=interrupt, daemon=True).start()
+t0 = time.monotonic()
+try:
+    NBMF(n_components=64, max_iter=10 ** 6, tol=0.0, random_state=7, n_gpus=4, devices=[0] * 4).fit(X)
+    out = {"interrupted": False}
+except KeyboardInterrupt:
+    out = {"interrupted": True, "seconds": time.monotonic() - t0,
+           "rank_threads_left": [t.name for t in threading.enumerate() if t.name.startswith("nbmf-rank-")]}
+# the device is free again: an ordinary fit runs
+est = NBMF(n_components=8, max_iter=5, tol=0.0, random_state=1).fit(X[:300, :200])
+out["next_fit_ok"] = bool(np.isfinite(est.loss_curve_[-1]))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_interrupted_caller_of_the_in_process_sharded_fit_stops_the_ranks():
+    """Ctrl-C in the thread that called ``NBMF(n_gpus=4).fit`` (a million iterations ahead of it): the four rank threads
+    are cancelled, leave their exchanges and close their contexts within the bound; KeyboardInterrupt reaches the caller;
+    no rank thread is left; the next fit in the same process runs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", NBMF_PEER_TIMEOUT_MS="20000")
+    r = subprocess.run([sys.executable, "-c", _INTERRUPT_SCRIPT, root], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert out["interrupted"] is True and out["rank_threads_left"] == [] and out["seconds"] < 60 and out["next_fit_ok"] is True

@@ -546,6 +546,31 @@ def test_perplexity_grid_matches_reference_driver(hip):
     assert abs(got - want) <= 1e-12 * want
 
 
+def test_heldout_perplexity_against_the_reference_drivers_own_value(hip, golden, both_small_paths):
+    """tests/golden/heldout.npz: the reference's fit on the training entries of a seeded 40 x 70 problem and its driver's
+    `compute_perplexity` (examples/reproduce_magron2022.py:40-47, run in the build container) on validation / test /
+    real-weight / no mask.  The device's strictly masked sweep on the REFERENCE's factors: <= 1e-12; the whole pipeline of
+    `perplexity_grid` (fit on train, evaluate on val and test): the reference's iteration count, loss <= 1e-10,
+    perplexities <= 1e-9 (200 ulp of accumulated fit difference at most)."""
+    from nbmf_mm_amd.experiments import heldout_perplexity, perplexity_grid
+    g = golden("heldout")
+    Y = g["Y"].astype(np.float64)
+    Wk, H = np.ascontiguousarray(g["W"].T), g["H"]
+    for name, mk in (("val", g["val"]), ("test", g["test"]), ("val_float", g["val"].astype(np.float64)),
+                     ("weights", g["weights"]), ("nomask", None)):
+        with hip.Context(40, 70, 5) as ev:
+            ev.set_hyper(1.0, 1.0)
+            ev.upload(Y, mask=mk)
+            got = heldout_perplexity(ev, Wk, H)
+        want = float(g["perp_" + name])
+        assert abs(got - want) <= 1e-12 * want, (name, got, want)
+    rows = perplexity_grid(Y, g["train"], {"val": g["val"], "test": g["test"]}, 5, [1.2], [1.2], max_iter=60, tol=1e-5)
+    assert len(rows) == 1 and rows[0]["n_iter"] == int(g["n_iter"])
+    assert abs(rows[0]["loss"] - g["losses"][-1]) <= 1e-10 * g["losses"][-1]
+    assert abs(rows[0]["val_perplexity"] - float(g["perp_val"])) <= 1e-9 * float(g["perp_val"])
+    assert abs(rows[0]["test_perplexity"] - float(g["perp_test"])) <= 1e-9 * float(g["perp_test"])
+
+
 @pytest.mark.parametrize("k", [5, 24, 40, 100])
 @pytest.mark.parametrize("masked", [False, True])
 def test_real_valued_data_with_a_binary_mask_every_sweep_variant(hip, k, masked):

@@ -296,3 +296,25 @@ def test_estimator_random_fixtures_through_the_restatement(golden):
         np.testing.assert_array_equal(H, c["H"], err_msg=str(par))
         n += 1
     assert n == 20
+
+
+def test_heldout_perplexity_of_the_reference_driver_bitwise(golden):
+    """examples/reproduce_magron2022.py:40-47 (`compute_perplexity`), compiled from the reference's source text by
+    oracle/make_golden.py in the build container and run on the reference's own fit of a seeded 40 x 70 problem:
+    the oracle's restatement gives the same bits for bool, 0/1 float and real-weight masks, no mask, and another eps
+    -- and the oracle's fit IS the reference's fit (factors bitwise), so the value is pinned end to end."""
+    g = golden("heldout")
+    Y = g["Y"].astype(np.float64)
+    W, H = g["W"], g["H"]
+    Y_hat = W @ H
+    assert orc.heldout_perplexity(Y, Y_hat, g["val"]) == float(g["perp_val"])
+    assert orc.heldout_perplexity(Y, Y_hat, g["test"]) == float(g["perp_test"])
+    assert orc.heldout_perplexity(Y, Y_hat, g["val"].astype(np.float64)) == float(g["perp_val_float"]) == float(g["perp_val"])
+    assert orc.heldout_perplexity(Y, Y_hat, g["weights"]) == float(g["perp_weights"])
+    assert orc.heldout_perplexity(Y, Y_hat) == float(g["perp_nomask"])
+    assert orc.heldout_perplexity(Y, Y_hat, g["test"], eps=1e-6) == float(g["perp_eps"])
+    Wo, Ho, losses, _, n_iter = orc.solve(Y, 5, max_iter=60, tol=1e-5, alpha=1.2, beta=1.2, mask=g["train"], random_state=12345)
+    assert n_iter == int(g["n_iter"])
+    np.testing.assert_array_equal(Wo, W)
+    np.testing.assert_array_equal(Ho, H)
+    np.testing.assert_array_equal(np.array(losses), g["losses"])
