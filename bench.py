@@ -33,6 +33,125 @@ ACHIEVABLE_HBM_GBPS = 6300.0   # ... of which a streaming copy reaches 6.29 TB/s
 #  region: nbmf_selftest_mfma_peak, a ~100 ms loop of nothing but v_mfma_f64_16x16x4_f64 with VGPR accumulators on all SIMDs)
 
 
+# ---- N > 1: bounds and the retry protocol ---------------------------------------------------------------
+# One attempt = one fresh worker process per rank (or per group of ranks).  The process the launcher started stays a
+# SUPERVISOR that never touches a GPU: if the attempt fails on ANY rank -- a transport that cannot exchange on this machine,
+# a set-up phase that runs into its bound, an exchange that times out in the timed region, a worker that dies -- every
+# worker leaves with EXIT_RETRY or an error, and every supervisor starts a second, fresh worker over the host transport,
+# whose line says what failed (config.transport_check).  Nothing is ever re-executed inside a process that has used the GPU.
+EXIT_RETRY = 75
+RDZV_TIMEOUT_S = 60.0          # the ranks of an attempt must all arrive within this
+SETUP_BOUND_S = float(os.environ.get("NBMF_BENCH_SETUP_BOUND_S", "100"))   # attach + self-test + trials + verification, summed:
+#   enforced by a watchdog thread in every worker (its pieces have bounds of their own -- peer attach: known-answer epochs
+#   <= 10 s; each probe wait <= 5 s; verification waits <= 5 s -- except RCCL's communicator set-up, which has none)
+ATTEMPT_TIMEOUT_S = float(os.environ.get("NBMF_BENCH_ATTEMPT_TIMEOUT_S", "600"))   # the supervisor's last resort per attempt
+
+
+class Watchdog:
+    """A phase that must end within a bound: `arm(seconds, what, on_fire)` starts the clock, `disarm()` stops it.  When it
+    runs out -- the main thread may sit in a device call or a collective for good -- `on_fire(what)` runs on the watchdog's
+    thread and must end the process (os._exit)."""
+
+    def __init__(self):
+        import threading
+        self._cv = threading.Condition()
+        self._deadline, self._what, self._on_fire, self.armed_for = None, None, None, 0.0
+        threading.Thread(target=self._loop, name="nbmf-bench-watchdog", daemon=True).start()
+
+    def arm(self, seconds, what, on_fire):
+        with self._cv:
+            self._deadline, self._what, self._on_fire, self.armed_for = time.monotonic() + seconds, what, on_fire, seconds
+            self._cv.notify()
+
+    def disarm(self):
+        with self._cv:
+            self._deadline = None
+            self._cv.notify()
+
+    def _loop(self):
+        with self._cv:
+            while True:
+                if self._deadline is None:
+                    self._cv.wait()
+                    continue
+                left = self._deadline - time.monotonic()
+                if left > 0:
+                    self._cv.wait(left)
+                    continue
+                fire, what = self._on_fire, self._what
+                self._deadline = None
+                break
+        fire(what)
+
+
+def write_note(text):
+    """Why this worker gives the attempt up: read by its supervisor, handed to the retry, printed on the retry's line."""
+    path = os.environ.get("NBMF_BENCH_NOTE")
+    if path:
+        try:
+            with open(path, "w") as f:
+                f.write(str(text)[:2000])
+        except OSError:
+            pass
+    print(f"[bench] rank {os.environ.get('RANK', '0')}: {text}", file=sys.stderr, flush=True)
+
+
+def supervise(argv, worker=None, attempt_timeout=None):
+    """The rank process as the launcher started it (N > 1): start a FRESH worker for this rank, wait for it, and if the
+    attempt failed start ONE more over the host transport.  Never touches a GPU itself.  `worker`: the command that is
+    started (default: this script again; the CPU tests pass a stand-in).  Returns the exit code."""
+    import signal
+    import tempfile
+    worker = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    limit = ATTEMPT_TIMEOUT_S if attempt_timeout is None else float(attempt_timeout)
+    child = {"p": None}
+
+    def forward(signum, _frame):              # the launcher ends the job: the worker must not outlive its supervisor
+        p = child["p"]
+        if p is not None and p.poll() is None:
+            p.kill()
+        raise SystemExit(128 + signum)
+    old = {sig: signal.signal(sig, forward) for sig in (signal.SIGTERM, signal.SIGINT)}
+    note = tempfile.NamedTemporaryFile(prefix="nbmf_bench_note_", suffix=".txt", delete=False)
+    note.close()
+    failed = None
+    try:
+        for attempt in (0, 1):
+            env = dict(os.environ, NBMF_BENCH_WORKER="1", NBMF_BENCH_ATTEMPT=str(attempt), NBMF_BENCH_NOTE=note.name,
+                       NBMF_RDZV_GENERATION=str(attempt))
+            args = list(argv)
+            if attempt == 1:
+                env["NBMF_BENCH_FAILED"] = failed
+                args += ["--transport", "host"]
+            open(note.name, "w").close()
+            p = child["p"] = subprocess.Popen(worker + args, env=env)
+            try:
+                code = p.wait(limit)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+                code = -9
+                with open(note.name, "w") as f:
+                    f.write(f"the worker did not end within the supervisor's last-resort limit of {limit:g} s")
+            if code == 0:
+                return 0
+            why = open(note.name).read().strip() or "no reason recorded"
+            failed = f"exit code {code}: {why}"
+            if attempt == 1 or "--transport host" in " ".join(argv):
+                print(f"[bench] rank {os.environ.get('RANK', '0')}: attempt {attempt} failed ({failed}); giving up", file=sys.stderr, flush=True)
+                return code if code > 0 else 1
+            print(f"[bench] rank {os.environ.get('RANK', '0')}: attempt 0 failed ({failed}); a fresh worker retries over the host transport",
+                  file=sys.stderr, flush=True)
+        return 1
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
+        try:
+            os.remove(note.name)
+        except OSError:
+            pass
+
+
 def make_shard(M, N, r0, r1, seed, density=0.25, observed=0.9, masked=True):
     """Rows [r0, r1) of the synthetic V / mask.  Generated per 4096-row block from
     default_rng([seed, block]) so that any sharding sees the same global matrix."""
@@ -253,20 +372,38 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     here = int(os.environ.get("NBMF_RANKS_IN_PROCESS", "1"))
-    if here == 1:
-        return run_rank(args, rank, local_rank, world)
-    # several ranks in this process: one thread each; any failure ends the process (and with it the job)
-    import threading
+    if world > 1 and not os.environ.get("NBMF_BENCH_WORKER"):
+        raise SystemExit(supervise(sys.argv[1:]))         # (this process never touches a GPU)
+    attempt = int(os.environ.get("NBMF_BENCH_ATTEMPT", "0"))
     import traceback
+
+    def give_up(t=None):
+        # the attempt is over for this worker: say why, and leave so that the supervisor can start the retry (attempt 0) or
+        # report the failure (the retry itself)
+        traceback.print_exc()
+        if world > 1 and attempt == 0:
+            write_note("".join(traceback.format_exception_only(*sys.exc_info()[:2])).strip())
+            os._exit(EXIT_RETRY)
+        os._exit(1)
+    if here == 1:
+        try:
+            return run_rank(args, rank, local_rank, world)
+        except SystemExit:
+            raise
+        except BaseException:
+            if world == 1:
+                raise
+            give_up()
+    # several ranks in this process: one thread each; any failure ends the process (and with it the attempt)
+    import threading
     failed = []
 
     def body(t):
         try:
             run_rank(args, rank + t, local_rank + t, world)
         except BaseException:
-            traceback.print_exc()
             failed.append(t)
-            os._exit(1)
+            give_up(t)
     threads = [threading.Thread(target=body, args=(t,)) for t in range(here)]
     for th in threads:
         th.start()
@@ -278,7 +415,14 @@ def main():
 
 def run_rank(args, rank, local_rank, world):
     from nbmf_mm_amd import _dist, _hip, _rendezvous
-    group = _rendezvous.init_from_env(rank=rank, world=world)   # plumbing only: handles / ids, barriers, max-over-ranks
+    group = _rendezvous.init_from_env(timeout=RDZV_TIMEOUT_S, rank=rank, world=world)   # plumbing only: handles / ids, barriers, max-over-ranks
+    attempt = int(os.environ.get("NBMF_BENCH_ATTEMPT", "0"))
+    dog = Watchdog() if world > 1 else None
+
+    def out_of_time(what):
+        # (watchdog thread; the main thread may be stuck for good.)  Attempt 0: the supervisors retry over the host transport.
+        write_note(f"set-up exceeded its bound of {dog.armed_for:g} s while: {what}")
+        os._exit(EXIT_RETRY if attempt == 0 else 1)
 
     M, N, K = (args.M * world if args.weak else args.M), args.N, args.K
     masked = not args.no_mask
@@ -323,20 +467,40 @@ def run_rank(args, rank, local_rank, world):
         ctx.set_factors(np.ascontiguousarray(W_full[:, r0:r1]), H0)
 
     reset()
-    transport, trials, transport_check = "none", None, None
+    transport, trials, transport_check, setup_s, shared, comm_seen = "none", None, None, None, False, None
     if world > 1:
+        # everything between here and the timed region that involves a transport -- attach, known-answer self-test, the
+        # trials, the verification against the host transport -- is ONE phase with ONE bound (setup_bound_s on the line)
+        t_setup = time.perf_counter()
+        dog.arm(SETUP_BOUND_S, "selecting and verifying the exchange transport", out_of_time)
+        # (fault injection for the tests of this very mechanism: the named rank never leaves the phase in attempt 0)
+        if attempt == 0 and os.environ.get("NBMF_BENCH_FAULT") == f"hang_in_setup:{rank}":
+            time.sleep(1e6)
+        shared = len(set(group.all_gather(dev_index))) < world
         if args.transport == "auto":
             # time a few iterations over each transport that attaches and keep the faster one (setup, untimed)
             # (RCCL refuses two ranks on one device -- and an attempt it refuses leaves its service threads behind, which
             #  on a box with 16 host cores for 8 ranks slowed the timed run sevenfold: where ranks share a card, as in a
             #  rehearsal on one GPU, it is not tried)
-            shared = len(set(group.all_gather(dev_index))) < world
             transport, trials = _dist.attach_fastest(ctx, group, reset, candidates=("peer", "peer2") + (() if shared else ("rccl",)))
         else:
             transport = _dist.attach_comm(ctx, group, args.transport)
         transport_check = None
         if transport != "host" and not args.no_verify:
-            transport, transport_check = verify_transport(ctx, group, reset, transport)
+            ctx.set_peer_timeout_ms(5000.0)           # (the verification's waits are probes too; the run gets the default back)
+            try:
+                transport, transport_check = verify_transport(ctx, group, reset, transport)
+            finally:
+                ctx.set_peer_timeout_ms(0.0)
+        if os.environ.get("NBMF_BENCH_FAILED"):
+            # this is the second attempt: say on the line what ended the first one, on which ranks
+            notes = group.all_gather(os.environ["NBMF_BENCH_FAILED"])
+            transport_check = ("attempt 0 FAILED and this line was measured by fresh workers over the host transport -- " +
+                               "; ".join(f"rank {r}: {n}" for r, n in enumerate(notes)))
+        info = ctx.comm_info()
+        comm_seen = {"kind": info["kind"], "nranks_seen": group.all_gather(info["nranks_seen"])}
+        dog.disarm()
+        setup_s = group.max_float(time.perf_counter() - t_setup)
     elif args.force_comm:
         transport = _dist.attach_comm(ctx, group, "rccl" if args.transport == "auto" else args.transport) + "(1 rank)"
 
@@ -389,7 +553,8 @@ def run_rank(args, rank, local_rank, world):
     if args.warmup > 0:
         ctx.run(args.warmup, 0.0)
     dt_other, losses_other = timed(args.steps)
-    ctx.close()
+    if world == 1:
+        ctx.close()               # (N > 1: the context stays for the extra RCCL leg, after the line has been put together)
     # the same data, factors and steps on the 8-byte storage path: what a real-valued V costs (the reference accepts any
     # V in [0, 1], _base.py:90; BASELINE's configs say "fp64 V"): two quotients and two logarithms per entry instead of
     # one reciprocal and no logarithm
@@ -482,6 +647,11 @@ def run_rank(args, rank, local_rank, world):
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "lane-mask records for the sweeps (2 bits per entry) + u8 tile codes for the per-lane kernels" if binary_path else ("f64 tiles + f64 weight tiles" if args.storage == "f64w" else "f64 tiles"),
                        "devices": devices,
                        "transport": transport, "transport_trials_s_per_5_iterations": trials, "transport_check": transport_check,
+                       "transport_sees": comm_seen, "attempt": attempt,
+                       "setup_s": setup_s, "setup_bound_s": SETUP_BOUND_S if world > 1 else None,
+                       "setup_bound_covers": ("attach + known-answer self-test + trials of every candidate + verification against the host "
+                                              "transport, summed; a watchdog in every worker ends an attempt that exceeds it and fresh "
+                                              "workers retry over the host transport") if world > 1 else None,
                        "sharding": (f"rows/{world} ({transport}: " + ("reduce-scatter of 2*K*N+1 doubles fused with the H-update, K*N back"
                                                              if transport.startswith("peer") else "all-reduce of 2*K*N+1 doubles"
                                                              + (" in two overlapped panels" if transport.endswith("2") else ""))
@@ -549,8 +719,53 @@ def run_rank(args, rank, local_rank, world):
                                            "tolerance": 1e-8}
             else:
                 out["parity_normalize"] = dict(out["parity"], pinned="oracle bitwise equal to the reference on tests/golden/*.npz")
+    if world > 1:
+        # north_star names RCCL; SURVEY 8 f4 names its replacement: the line carries BOTH.  Whatever transport won, RCCL is
+        # timed over the same steps from the same state whenever the ranks sit on distinct devices (it refuses two ranks on
+        # one), and says itself how many ranks its communicator joins (ncclCommCount).  The line is complete before this leg
+        # starts: if the leg runs into its bound the watchdog prints the line without it -- a measurement is never lost to it.
+        def add_rccl(rec):
+            if rank == 0:
+                out["rccl_value"] = rec["value"]
+                out["rccl_nranks"] = rec["nranks_seen"]
+                out["rccl"] = rec
+
+        def rccl_leg_out_of_time(what):
+            write_note(f"the extra RCCL leg exceeded {dog.armed_for:g} s; the line goes out without it")
+            if rank == 0:
+                add_rccl({"value": None, "nranks_seen": None, "remote": None, "error": f"{what}: no answer within {dog.armed_for:g} s"})
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        none = {"value": None, "nranks_seen": None, "remote": None}
+        if transport in ("rccl", "rccl2"):
+            rccl = dict(none, value=args.steps / dt, nranks_seen=comm_seen["nranks_seen"], error=None, note="RCCL is the transport of this line")
+        elif attempt > 0 or args.transport == "host":
+            rccl = dict(none, error="not timed: this line runs over the host transport")
+        elif shared:
+            rccl = dict(none, error="not timed: ranks share a device (a rehearsal on one GPU), and RCCL refuses two ranks on one device")
+        elif trials is not None and "rccl" not in trials:
+            rccl = dict(none, error="RCCL did not attach, or could not exchange, in the selection's trial")
+        else:
+            dog.arm(SETUP_BOUND_S, "timing RCCL beside the chosen transport", rccl_leg_out_of_time)
+            try:
+                ctx.comm_detach()
+                ctx.set_hyper(1.2, 1.2, 1e-8, proj)
+                rccl = _dist.time_transport(ctx, group, reset, "rccl", args.steps, args.warmup)
+            except BaseException as e:       # noqa: BLE001  (a rank that died, a broken rendezvous: the line still goes out, and
+                dog.disarm()                 #  nobody asks for a retry of an attempt whose measurement is complete)
+                add_rccl(dict(none, error=f"{type(e).__name__}: {e}"))
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            dog.disarm()
+        add_rccl(rccl)
+        ctx.close()
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    group.close()
+    try:
+        group.close()
+    except Exception:                # noqa: BLE001  (the line is out: a rank that is already gone must not turn it into a failure)
+        pass
 
 
 if __name__ == "__main__":

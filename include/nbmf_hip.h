@@ -160,6 +160,11 @@ int nbmf_batch_stats(nbmf_ctx* ctx, int* launches, int* problems);
  * the W-pass and the row blocks (16 rows of the swept image) per chunk; a sweep launches (column strips / 4) x chunks
  * workgroups.  Any pointer may be NULL. */
 int nbmf_sweep_info(nbmf_ctx* ctx, int* h_chunks, int* h_blocks_per_chunk, int* w_chunks, int* w_blocks_per_chunk);
+/* Diagnostics, process-wide: sweeps launched in the two-state W variant (binary data observed everywhere, no pad rows in the
+ * swept dimension: the bracket of _solver.py:53 with two states per entry instead of three) and in the ragged-K variant
+ * (fewer components than the layout holds).  Tests use it to make sure the variant they mean to test is the one that ran.
+ * Any pointer may be NULL. */
+int nbmf_variant_stats(long long* full_w_launches, long long* ragged_k_launches);
 
 /* Progress reports while nbmf_run works (the `verbose` prints of _solver.py:165-166 need the losses as they
  * arrive, not after the run): with a callback set, nbmf_run synchronises after every `every` iterations and

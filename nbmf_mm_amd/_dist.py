@@ -194,6 +194,54 @@ def attach_fastest(ctx, group, reset, shard_axis=0, candidates=("peer", "rccl"),
     return best, timings
 
 
+def time_transport(ctx, group, reset, name, steps, warmup=2, shard_axis=0):
+    """One timed leg over transport ``name``, whatever transport the job itself runs on: attach it on every rank, ask it what
+    it sees (``ctx.comm_info()``), run ``warmup`` + ``steps`` iterations from ``reset()``'s state, detach.  Collective and
+    symmetric under partial failure like :func:`attach_fastest`.  Returns the same dict on every rank:
+    ``{"value": iterations per second (max time over ranks) or None, "nranks_seen": [what each rank's communicator reports],
+    "remote": [...], "error": None or the first rank's message}`` -- ``bench.py`` puts RCCL's on its line (``rccl_value``,
+    ``rccl_nranks``) even when another transport won the selection."""
+    import time
+    out = {"value": None, "nranks_seen": None, "remote": None, "error": None}
+    try:
+        attach_comm(ctx, group, name, shard_axis)
+    except _REFUSED as e:                         # refused on some rank: every rank got the same answer from the vote ...
+        msgs = group.all_gather(str(e))           # ... but only the rank(s) it failed on know why: the line quotes those
+        own = [f"rank {r}: {m}" for r, m in enumerate(msgs) if "another rank" not in m]
+        out["error"] = f"{name} did not attach -- " + "; ".join(own or msgs[:1])
+        return out
+    info, err, t = {"nranks_seen": None, "remote": None}, None, float("inf")
+    try:
+        info = ctx.comm_info()
+        reset()
+        if warmup > 0:
+            ctx.run(int(warmup), 0.0)
+        ctx.synchronize()
+    except _REFUSED as e:
+        err = f"warm-up over {name} failed: {e}"
+    ok = group.agree(err is None)
+    if ok:
+        group.barrier()
+        try:
+            t0 = time.perf_counter()
+            ctx.run(int(steps), 0.0)
+            ctx.synchronize()
+            t = time.perf_counter() - t0
+        except _REFUSED as e:
+            err = f"timed run over {name} failed: {e}"
+    t = group.max_float(t)
+    ok = group.agree(err is None)
+    ctx.comm_detach()
+    table = group.all_gather((info.get("nranks_seen"), info.get("remote"), err))
+    out["nranks_seen"] = [row[0] for row in table]
+    out["remote"] = [row[1] for row in table]
+    if ok:
+        out["value"] = int(steps) / t
+    else:
+        out["error"] = next((f"rank {r}: {row[2]}" for r, row in enumerate(table) if row[2]), "failed on another rank")
+    return out
+
+
 def fit_row_sharded(Y_local, M_global, r0, n_components, group, max_iter=500, tol=1e-5, alpha=1.2, beta=1.2,
                     W_init=None, H_init=None, mask_local=None, random_state=None, eps=1e-8,
                     projection="normalize", device=0, transport="auto"):

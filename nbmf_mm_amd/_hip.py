@@ -36,7 +36,7 @@ SYMBOLS = [
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
     "nbmf_set_progress", "nbmf_device_synchronize", "nbmf_small_stats", "nbmf_generate_slice", "nbmf_set_storage",
     "nbmf_set_exchange_panels", "nbmf_set_peer_timeout_ms", "nbmf_run_batch", "nbmf_batch_stats", "nbmf_sweep_info",
-    "nbmf_upload_v", "nbmf_selftest_mfma_peak", "nbmf_engine_stats", "nbmf_source_hash", "nbmf_comm_info", "nbmf_cancel",
+    "nbmf_upload_v", "nbmf_selftest_mfma_peak", "nbmf_engine_stats", "nbmf_source_hash", "nbmf_comm_info", "nbmf_cancel", "nbmf_variant_stats",
 ]
 DATA_F64, DATA_U8, DATA_F32 = 0, 1, 2
 
@@ -127,6 +127,7 @@ def load():
     lib.nbmf_abi_version.restype = c_int
     lib.nbmf_source_hash.restype = c_char_p
     lib.nbmf_cancel.argtypes = [c_void_p]
+    lib.nbmf_variant_stats.argtypes = [POINTER(ctypes.c_longlong), POINTER(ctypes.c_longlong)]
     lib.nbmf_comm_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     lib.nbmf_last_error.restype = c_char_p
     lib.nbmf_device_count.argtypes = [POINTER(c_int)]
@@ -512,6 +513,13 @@ def engine_stats():
     a, b, c = ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
     _check(load().nbmf_engine_stats(byref(a), byref(b), byref(c)))
     return a.value, b.value, c.value
+
+
+def variant_stats():
+    """Process-wide: (sweeps launched in the two-state W variant, sweeps launched in the ragged-K variant)."""
+    a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    _check(load().nbmf_variant_stats(byref(a), byref(b)))
+    return a.value, b.value
 
 
 def mfma_peak(device=0, target_ms=100.0):

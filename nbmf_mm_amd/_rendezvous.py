@@ -592,6 +592,8 @@ def init_from_env(timeout=300.0, collective_timeout=None, rank=None, world=None)
     if os.environ.get("NBMF_RDZV_PORT"):
         address = ("tcp", host, int(os.environ["NBMF_RDZV_PORT"]))
     else:
-        # restarts by an elastic launcher get a fresh name: a relay of the previous attempt may still be closing
-        address = ("unix", f"nbmf-rdzv-{port}-{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}")
+        # restarts by an elastic launcher, and bench.py's own second attempt (NBMF_RDZV_GENERATION), get a fresh name: a relay
+        # of the previous attempt may still be closing
+        address = ("unix", f"nbmf-rdzv-{port}-{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
+                           f"-{os.environ.get('NBMF_RDZV_GENERATION', '0')}")
     return Group(rank, world, address, timeout=timeout, collective_timeout=collective_timeout)

@@ -773,12 +773,15 @@ hipError_t log_table_device(const double2** out) {
 // configs[1] cost ~4.5 us each, 5 % of the iteration); EvScope puts them here, the next pass launch of this thread
 // takes them.  Sweeps of several launches are bracketed by recorded events as before.
 thread_local hipEvent_t tl_attach_start = nullptr, tl_attach_stop = nullptr;
-template <int KB, int DATA, int MODE, int TH, bool TINY, bool RAG = false>
+std::atomic<long long> g_full_w_launches{0}, g_ragged_launches{0};   // nbmf_variant_stats
+template <int KB, int DATA, int MODE, int TH, bool TINY, bool RAG = false, bool FULL = false>
 hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
+  if (FULL) g_full_w_launches.fetch_add(1, std::memory_order_relaxed);
+  if (RAG) g_ragged_launches.fetch_add(1, std::memory_order_relaxed);
   dim3 grid(a_.Cb / WG_WAVES, chunks);
   constexpr int lds_bytes = pass_lds_bytes(KB, DATA, MODE);
   if (lds_bytes > 65536) {
-    hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH, TINY, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)pass_kernel<KB, DATA, MODE, TH, TINY, RAG, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
   }
   PassArgs a = a_;
@@ -799,7 +802,7 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
     hipError_t e = dmalloc(&tr, sizeof(unsigned long long) * 8 * n_wg);
     if (e != hipSuccess) return e;
     a.trace = tr;
-    hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY, RAG>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
+    hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY, RAG, FULL>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
     std::vector<unsigned long long> h(8 * n_wg);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -854,10 +857,10 @@ hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
   if (tl_attach_start) {
     hipEvent_t e0 = tl_attach_start, e1 = tl_attach_stop;
     tl_attach_start = tl_attach_stop = nullptr;
-    hipExtLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY, RAG>), grid, dim3(64 * WG_WAVES), lds_bytes, st, e0, e1, 0, a);
+    hipExtLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY, RAG, FULL>), grid, dim3(64 * WG_WAVES), lds_bytes, st, e0, e1, 0, a);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY, RAG>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
+  hipLaunchKernelGGL((pass_kernel<KB, DATA, MODE, TH, TINY, RAG, FULL>), grid, dim3(64 * WG_WAVES), lds_bytes, st, a);
   return hipGetLastError();
 }
 // (eps below 1e-70 on the binary path: the variant with per-entry reciprocals and renormalisation, see pass_kernel)
@@ -871,14 +874,22 @@ hipError_t launch_pass_t(const PassArgs& a, int chunks, hipStream_t st) {
   // at least a twelfth of the tile's MFMAs goes (k = 50: three of 48, -1.7 %), and not on the general path at K <= 16 (four
   // tiles per stage with branches between their MFMAs: 250 registers and scratch, -4 % at k = 10).
   constexpr bool HAS_RAG = TH == 0 && MODE != MODE_T && KB <= 4 && (DATA == DATA_BIN || KB >= 2);
+  // W sweeps over a matrix that is observed everywhere and has no pad rows in the swept dimension: the two-state variant
+  // (FULL, nbmf_pass_kernel.inc; NBMF_NO_FULL_W=1: the three-state kernels on such data -- tests)
+  constexpr bool HAS_FULL = TH == 0 && MODE == MODE_W && DATA == DATA_BIN;
+  static const bool no_full = getenv("NBMF_NO_FULL_W") != nullptr;
+  const bool full = HAS_FULL && a.full && !no_full;
   static const bool no_rag = getenv("NBMF_NO_RAGGED_K") != nullptr;   // (tests: the full-K kernels on a ragged K -- the same bits)
   if (HAS_RAG && !no_rag && a.ksteps > 0 && a.ksteps < 4 * KB) {
     const int per_block = MODE == MODE_H ? 8 : (MODE == MODE_W ? 4 : 0);   // back-product MFMAs of one 16-block of components
     const int skipped = (4 * KB - a.ksteps) + (KB >= 4 ? (KB - a.kblocks) * per_block : 0);
     const int total = 4 * KB + KB * per_block;
-    if (12 * skipped >= total) return launch_pass_tt<KB, DATA, MODE, TH, false, HAS_RAG>(a, chunks, st);
+    if (12 * skipped >= total)
+      return full ? launch_pass_tt<KB, DATA, MODE, TH, false, HAS_RAG, HAS_RAG && HAS_FULL>(a, chunks, st)
+                  : launch_pass_tt<KB, DATA, MODE, TH, false, HAS_RAG>(a, chunks, st);
   }
-  return launch_pass_tt<KB, DATA, MODE, TH, false>(a, chunks, st);
+  return full ? launch_pass_tt<KB, DATA, MODE, TH, false, false, HAS_FULL>(a, chunks, st)
+              : launch_pass_tt<KB, DATA, MODE, TH, false>(a, chunks, st);
 }
 
 // n_components > 128: the sweep of one slice with Theta read from memory (TH = 1: whole; TH = 2: the earlier
@@ -1448,6 +1459,9 @@ PassArgs w_pass_args(nbmf_ctx* c) {
   a.C_alloc = c->mA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c) || c->w_free;   // (transform's W steps start from a W that is not on the simplex: the select variant)
+  // every entry observed (no mask, or a mask of ones) and no pad rows in the dimension the W sweep walks (the columns of Y):
+  // a pad there would count as an observed zero in the two-state variant's column sums
+  a.full = c->data_kind == DATA_BIN && c->n_obs == (double)c->m * (double)c->n && c->nA == c->n;
   a.ksteps = (c->k + 3) / 4;
   a.kblocks = (c->k + 15) / 16;
   return a;
@@ -1965,6 +1979,32 @@ void small_common_args(const nbmf_ctx* c, int max_iter, double tol, SmallArgs* o
   double ms = 2000.0;
   if (const char* e = getenv("NBMF_SMALL_TIMEOUT_MS")) ms = std::max(1.0, atof(e));
   a.timeout = (unsigned long long)(ms * 1e5);
+  if (const char* e = getenv("NBMF_SMALL_FENCED")) a.fenced = atoi(e) != 0;   // release / acquire around every hand-off (nbmf_small_kernel.inc: small_arrive)
+}
+
+// END-OF-RUN GUARD of the single-launch engine (round 6).  Its hand-offs are the guide's measured sc1 form, not the memory
+// model's release / acquire (which costs more than a phase: DESIGN.md 4.4): a stale read would be a silent wrong answer.
+// What CAN be checked from outside at the price of two small launches: the last loss the persistent kernel reported was
+// formed from the factors as its workgroups SAW them across the final hand-offs; the launch-per-kernel engine recomputes
+// the loss of the factors as they ARE in memory (a kernel boundary: no hand-off involved).  The two engines agree to
+// 1e-12 relative when nothing went wrong (different summation orders; tests/test_gpu_parity.py holds them to that), a stale
+// factor entry in the last sweep moves the loss by far more unless the fit has converged to that very precision.  A
+// mismatch is treated like an abandoned barrier: the run is redone by the launches from the snapshot and counted
+// (nbmf_engine_stats: gave_up).  NBMF_SMALL_GUARD=0 switches the check off; NBMF_SMALL_GUARD_FAULT=1 (tests) makes it trip.
+int loss_by_launches(nbmf_ctx* c, double* out);
+bool small_guard_on() {
+  static const bool on = !(getenv("NBMF_SMALL_GUARD") && atoi(getenv("NBMF_SMALL_GUARD")) == 0);
+  return on;
+}
+int small_guard(nbmf_ctx* c, double reported, bool* ok) {
+  double chk = 0.0;
+  if (int rc = loss_by_launches(c, &chk)) return rc;
+  if (getenv("NBMF_SMALL_GUARD_FAULT")) chk += 1e-6 * std::fabs(chk) + 1e-300;
+  *ok = (std::isnan(chk) && std::isnan(reported)) || chk == reported ||
+        std::fabs(chk - reported) <= 1e-12 * std::max(std::fabs(chk), std::fabs(reported));
+  if (!*ok && getenv("NBMF_DEBUG"))
+    fprintf(stderr, "[nbmf] single-launch guard: reported loss %.17g, recomputed %.17g: redone by the launches\n", reported, chk);
+  return NBMF_OK;
 }
 
 // Returns NBMF_OK with *handled = true when the run is complete (losses, n_iter filled, factors in the context's
@@ -2080,12 +2120,10 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   HIPCHK(hipMemcpyAsync(&abort_word, w.sync + a.G, sizeof abort_word, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(stream_wait_spin(c->stream));
   ++w.runs;
-  if (res[2] != 0 || abort_word != 0 || res[0] < 1 || res[0] > max_iter) {
-    // a barrier was abandoned (workgroups not co-resident for too long): back to the state at entry, and this
-    // context keeps to the five-kernel path from now on
+  auto back_to_entry = [&](bool disable) -> int {
     ++w.aborted;
     g_engine_persistent_aborted.fetch_add(1, std::memory_order_relaxed);
-    w.disabled = true;
+    if (disable) w.disabled = true;
     HIPCHK(hipMemcpyAsync(c->Wn, w.snapW, fw, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->Hn, w.snapH, fh, hipMemcpyDeviceToDevice, c->stream));
     const long long tw = (long long)c->KP * c->mA, th = (long long)c->KP * c->nA;
@@ -2096,8 +2134,13 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
                        c->HT, c->HG, c->KP, c->KP, (long long)c->nA);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (getenv("NBMF_DEBUG")) fprintf(stderr, "[nbmf] persistent fit abandoned (status %d, abort word %llu): five-kernel path\n", res[2], abort_word);
     return NBMF_OK;
+  };
+  if (res[2] != 0 || abort_word != 0 || res[0] < 1 || res[0] > max_iter) {
+    // a barrier was abandoned (workgroups not co-resident for too long): back to the state at entry, and this
+    // context keeps to the five-kernel path from now on
+    if (getenv("NBMF_DEBUG")) fprintf(stderr, "[nbmf] persistent fit abandoned (status %d, abort word %llu): five-kernel path\n", res[2], abort_word);
+    return back_to_entry(/*disable=*/true);
   }
   if (res[1] == 0) {   // the final factors sit in the second set of images
     HIPCHK(hipMemcpyAsync(c->Wn, w.Wn, fw, hipMemcpyDeviceToDevice, c->stream));
@@ -2109,6 +2152,11 @@ int run_small(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter
   }
   HIPCHK(hipMemcpyAsync(losses, c->losses_d, sizeof(double) * (size_t)res[0], hipMemcpyDeviceToHost, c->stream));
   HIPCHK(stream_wait_spin(c->stream));
+  if (small_guard_on()) {   // (see small_guard: the last loss as reported against the loss of the factors as they are in memory)
+    bool ok = true;
+    if (int rc = small_guard(c, losses[res[0] - 1], &ok)) return rc;
+    if (!ok) return back_to_entry(/*disable=*/false);   // *handled stays false: the launches redo the run from the state at entry
+  }
   *n_iter = res[0];
   *handled = true;
   g_engine_persistent_served.fetch_add(1, std::memory_order_relaxed);
@@ -2412,6 +2460,24 @@ int set_device(nbmf_ctx* c) {
   return NBMF_OK;
 }
 
+// (also the single-launch engine's end-of-run guard: small_guard)
+int loss_by_launches(nbmf_ctx* c, double* loss) {
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_losses(c, 1)) return rc;
+  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
+  hipLaunchKernelGGL(prior_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Hn, c->prior, c->k, c->KP,
+                     (long long)c->n, (long long)c->nA, c->eps);
+  HIPCHK(hipGetLastError());
+  c->prior_src = c->prior;
+  c->n_prior_src = c->n_prior_blocks;
+  if (int rc = enqueue_loglik_pass(c, 0)) return rc;
+  if (int rc = enqueue_finalize(c, 0, 0.0)) return rc;
+  HIPCHK(hipMemcpyAsync(loss, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->timing) timing_collect(c);
+  return peer_check(c);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -2419,7 +2485,7 @@ int set_device(nbmf_ctx* c) {
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-int nbmf_abi_version(void) { return 4; }   // 2: NBMF_PEER_HANDLE_BYTES 128 -> 192, nbmf_generate_slice, nbmf_set_storage; 3: nbmf_upload_v (uint8 / bool data), nbmf_selftest_mfma_peak, nbmf_engine_stats; 4: nbmf_source_hash, nbmf_comm_info, nbmf_cancel
+int nbmf_abi_version(void) { return 4; }   // 2: NBMF_PEER_HANDLE_BYTES 128 -> 192, nbmf_generate_slice, nbmf_set_storage; 3: nbmf_upload_v (uint8 / bool data), nbmf_selftest_mfma_peak, nbmf_engine_stats; 4: nbmf_source_hash, nbmf_comm_info, nbmf_cancel, nbmf_variant_stats
 // The sources this binary was compiled from: first 12 hex digits of the SHA-256 over nbmf_hip.hip, the *.inc files (sorted
 // by name) and include/nbmf_hip.h, put in by the Makefile (tools/src_hash.sh prints the same for the tree).  A profile or a
 // bench line that quotes it can be tied to a commit; a library built by hand without the Makefile says "unstamped".
@@ -3088,6 +3154,12 @@ int nbmf_sweep_info(nbmf_ctx* c, int* h_chunks, int* h_blocks, int* w_chunks, in
   return NBMF_OK;
 }
 
+int nbmf_variant_stats(long long* full_w_launches, long long* ragged_k_launches) {
+  if (full_w_launches) *full_w_launches = g_full_w_launches.load(std::memory_order_relaxed);
+  if (ragged_k_launches) *ragged_k_launches = g_ragged_launches.load(std::memory_order_relaxed);
+  return NBMF_OK;
+}
+
 int nbmf_w_only_steps(nbmf_ctx* c, int n_steps) {
   if (int rc = ready(c)) return rc;
   if (n_steps < 0) return fail(NBMF_ERR_ARG, "n_steps must be >= 0");
@@ -3115,22 +3187,8 @@ int nbmf_w_only_steps(nbmf_ctx* c, int n_steps) {
 int nbmf_loss(nbmf_ctx* c, double* loss) {
   if (int rc = ready(c)) return rc;
   if (!loss) return fail(NBMF_ERR_ARG, "null output");
-  if (int rc = set_device(c)) return rc;
-  if (int rc = ensure_losses(c, 1)) return rc;
-  HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int) * 8, c->stream));
-  hipLaunchKernelGGL(prior_kernel, dim3(c->n_prior_blocks), dim3(256), 0, c->stream, c->Hn, c->prior, c->k, c->KP,
-                     (long long)c->n, (long long)c->nA, c->eps);
-  HIPCHK(hipGetLastError());
-  c->prior_src = c->prior;
-  c->n_prior_src = c->n_prior_blocks;
-  if (int rc = enqueue_loglik_pass(c, 0)) return rc;
-  if (int rc = enqueue_finalize(c, 0, 0.0)) return rc;
-  HIPCHK(hipMemcpyAsync(loss, c->losses_d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (c->timing) timing_collect(c);
-  return peer_check(c);
+  return loss_by_launches(c, loss);
 }
-
 int nbmf_loglik(nbmf_ctx* c, int clip_theta, double* loglik) {
   if (int rc = ready(c)) return rc;
   if (!loglik) return fail(NBMF_ERR_ARG, "null output");

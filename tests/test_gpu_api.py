@@ -560,6 +560,46 @@ def test_run_batch_falls_back_when_a_launch_gives_up(monkeypatch):
         np.testing.assert_allclose(redo[3][p], good[3][p], rtol=0, atol=1e-12)
 
 
+def test_single_launch_guard_and_fenced_handoff(monkeypatch):
+    """Round 6, the single-launch engine's hand-off.  (a) NBMF_SMALL_FENCED=1 puts an agent-scope release in
+    front of every flag store and an acquire behind every poll -- the memory model's own form on top of the sc1 form --:
+    the same arithmetic, so the same bits, still served by the persistent kernel.  (b) The end-of-run guard: the last loss
+    the persistent kernel reported against the loss of the final factors recomputed by the launch-per-kernel engine (1e-12
+    relative, the two engines' tested agreement); made to trip (NBMF_SMALL_GUARD_FAULT=1) the run is redone by the launches
+    from the state at entry -- the five-kernel path's own bits -- and counted as given up; left alone it never trips over
+    shapes, storage paths, stop rules and continued runs."""
+    from nbmf_mm_amd import _hip
+    r = np.random.default_rng(18)
+    for (m, n, k, real) in [(100, 500, 6, False), (1226, 285, 8, False), (253, 902, 16, False), (77, 130, 20, True), (1500, 900, 12, False)]:
+        Y = r.random((m, n)) if real else (r.random((m, n)) < 0.3).astype(np.float64)
+        mask = r.random((m, n)) < 0.85
+        W0 = r.uniform(0.1, 0.9, (k, m))
+        W0 /= W0.sum(axis=0, keepdims=True)
+        H0 = r.uniform(0.1, 0.9, (k, n))
+        out = {}
+        for mode in ("plain", "fenced", "five", "guard_trips"):
+            monkeypatch.setenv("NBMF_PERSISTENT", "0" if mode == "five" else "1")
+            for var, on in (("NBMF_SMALL_FENCED", mode == "fenced"), ("NBMF_SMALL_GUARD_FAULT", mode == "guard_trips")):
+                if on:
+                    monkeypatch.setenv(var, "1")
+                else:
+                    monkeypatch.delenv(var, raising=False)
+            with _hip.Context(m, n, k) as ctx:
+                ctx.set_hyper(1.1, 1.3, 1e-8)
+                ctx.upload(Y, mask=mask)
+                ctx.set_factors(W0, H0)
+                l1, _ = ctx.run(30, 0.0)
+                l2, n2 = ctx.run(300, 1e-5)
+                out[mode] = (np.concatenate([l1, l2]), n2) + ctx.get_factors() + (ctx.small_stats(),)
+        assert out["plain"][4] == (2, 0) and out["fenced"][4] == (2, 0) and out["five"][4] == (0, 0)
+        assert out["guard_trips"][4] == (2, 2)                  # both runs served, both refused by the guard and redone
+        for j in (0, 2, 3):
+            np.testing.assert_array_equal(out["fenced"][j], out["plain"][j])
+            np.testing.assert_array_equal(out["guard_trips"][j], out["five"][j])
+        assert out["plain"][1] == out["fenced"][1] == out["five"][1] == out["guard_trips"][1]
+        np.testing.assert_allclose(out["plain"][0], out["five"][0], rtol=1e-12, atol=0)
+
+
 def test_n_init_restarts_share_one_batched_call():
     """NBMF(n_init=r): the restarts go up as one nbmf_run_batch call; the winner is bit for bit the best of the
     sequential fits with seeds random_state, random_state + 1, ... (README.md:144)."""

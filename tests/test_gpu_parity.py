@@ -1001,3 +1001,59 @@ def test_seeded_sweep_of_configurations_vs_oracle(hip, both_small_paths):
         np.testing.assert_allclose(l, lr, rtol=1e-9 if duchi else LOSS_RTOL, atol=0, err_msg=tag)
         np.testing.assert_allclose(W, Wr, rtol=0, atol=FACTOR_ATOL, err_msg=tag)
         np.testing.assert_allclose(H, Hr, rtol=0, atol=FACTOR_ATOL, err_msg=tag)
+
+
+_FULL_W_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from nbmf_mm_amd import _hip, nbmf_mm_solver
+g = np.random.default_rng(61)
+out = {}
+for name, (m, n), K in (("k8", (700, 512), 8), ("k10", (700, 512), 10), ("k16", (333, 256), 16), ("k32", (700, 512), 32), ("k40", (520, 384), 40),
+                        ("k64", (700, 512), 64), ("k100", (300, 256), 100), ("padded_n", (700, 500), 32)):
+    X = (g.random((m, n)) < 0.3).astype(np.float64)
+    before = _hip.variant_stats()[0]
+    W, H, l, _, _ = nbmf_mm_solver(X, K, max_iter=12, tol=0, random_state=1, alpha=1.2, beta=1.3)
+    one = nbmf_mm_solver(X, K, max_iter=1, tol=0, random_state=1, alpha=1.2, beta=1.3)
+    out[name] = {"losses": [float(v) for v in l], "W": W.ravel()[::7].tolist(), "H": H.ravel()[::7].tolist(),
+                 "W1": one[0].ravel()[::5].tolist(), "full_launches": _hip.variant_stats()[0] - before}
+# dir-beta: the W sweep walks the ROWS of V
+X = (g.random((512, 300)) < 0.3).astype(np.float64)
+before = _hip.variant_stats()[0]
+W, H, l, _, _ = nbmf_mm_solver(X, 24, max_iter=8, tol=0, random_state=2, orientation="dir-beta")
+out["dir_beta"] = {"losses": [float(v) for v in l], "W": W.ravel()[::7].tolist(), "H": H.ravel()[::7].tolist(), "W1": [],
+                   "full_launches": _hip.variant_stats()[0] - before}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_two_state_w_sweep_on_fully_observed_data_equals_the_three_state_sweep(hip):
+    """Binary data observed everywhere, no pad rows in the dimension the W sweep walks: the W sweeps run in the two-state
+    (FULL) variant -- an entry that is not a one IS an observed zero, no "observed" factor, four words of lane masks per
+    tile.  Against the three-state kernels on the same data (NBMF_NO_FULL_W=1): one step's W <= 1e-13, twelve iterations'
+    losses <= 1e-12 relative, factors <= 1e-11; the variant is used where it applies (every layout, ragged K, dir-beta) and
+    NOT where the swept dimension is padded (500 columns: a pad would count as an observed zero in the column sums).  Both
+    runs against the oracle are covered by every other test of this file (unmasked data takes the variant by default)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for no_full in (False, True):
+        env = dict(os.environ, NBMF_PERSISTENT="0")
+        env.pop("NBMF_NO_FULL_W", None)
+        if no_full:
+            env["NBMF_NO_FULL_W"] = "1"
+        r = subprocess.run([sys.executable, "-c", _FULL_W_SCRIPT, root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        res.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]))
+    full, three = res
+    assert full.keys() == three.keys() and len(full) == 9
+    for name in full:
+        assert three[name]["full_launches"] == 0
+        assert (full[name]["full_launches"] == 0) == (name == "padded_n"), name
+        np.testing.assert_allclose(full[name]["losses"], three[name]["losses"], rtol=1e-12, atol=0, err_msg=name)
+        np.testing.assert_allclose(full[name]["W1"], three[name]["W1"], rtol=0, atol=1e-13, err_msg=name)
+        np.testing.assert_allclose(full[name]["W"], three[name]["W"], rtol=0, atol=1e-11, err_msg=name)
+        np.testing.assert_allclose(full[name]["H"], three[name]["H"], rtol=0, atol=1e-11, err_msg=name)

@@ -308,6 +308,41 @@ def test_bench_is_bounded_when_the_peer_transport_attaches_nowhere():
     assert not line["config"]["transport"].startswith("peer")          # the faulty transport was not chosen
     assert "peer" not in (line["config"]["transport_trials_s_per_5_iterations"] or {})
     assert wall < 90.0, f"transport selection with a dead peer transport took {wall:.0f} s"
+    # the self-evidencing fields of an N > 1 line: the bound on the transport phase and what it took, what the transport in
+    # use says about the job, and RCCL's own entry -- here "not timed", with the reason (two ranks on one device)
+    cfg = line["config"]
+    assert cfg["attempt"] == 0 and cfg["setup_bound_s"] == 100.0 and 0.0 < cfg["setup_s"] < cfg["setup_bound_s"]
+    assert cfg["transport_sees"] == {"kind": "host", "nranks_seen": [2, 2]}
+    assert line["rccl_value"] is None and line["rccl_nranks"] is None and "share a device" in line["rccl"]["error"]
+    assert line["library"]["source_hash"] == line["library"]["tree_source_hash"]
+
+
+def test_bench_line_still_comes_out_when_a_rank_never_leaves_the_transport_phase():
+    """A rank that hangs while the transport is being selected (fault injection in bench.py: rank 1 of attempt 0 sleeps for
+    good; rank 0 waits for it in a collective): both workers' watchdogs end the attempt at the phase's bound (15 s here, 100 s
+    by default), both supervisors -- which never touch the GPU -- start FRESH workers over the host transport, and the line
+    comes out with `transport_check` saying what failed on which rank."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NBMF_BENCH_FAULT="hang_in_setup:1", NBMF_BENCH_SETUP_BOUND_S="15")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--M", "4096", "--N", "2048",
+                        "--K", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line, cfg = lines[0], lines[0]["config"]
+    assert line["n_gpus"] == 2 and line["replicas_identical"] is True and line["loss_monotone"] is True and line["value"] > 0
+    assert cfg["transport"] == "host" and cfg["attempt"] == 1
+    assert "attempt 0 FAILED" in cfg["transport_check"] and "rank 1: exit code 75: set-up exceeded its bound of 15 s" in cfg["transport_check"]
+    assert "rank 0: exit code" in cfg["transport_check"]
+    assert "host transport" in line["rccl"]["error"]
+    assert wall < 120.0, f"{wall:.0f} s"
 
 
 _N_GPUS_SCRIPT = r"""
