@@ -968,7 +968,9 @@ int resident_per_cu(int KB, int data_kind) {
 void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int cus, bool one_round_ok, int* chunks, int* CH) {
   (void)slots;
   int target = 2048;
-  if (const char* e = getenv("NBMF_TARGET_WGS")) target = std::max(1, atoi(e));
+  const char* te = getenv(one_round_ok ? "NBMF_TARGET_WGS_H" : "NBMF_TARGET_WGS_W");   // (tuning experiments: one sweep only)
+  if (!te) te = getenv("NBMF_TARGET_WGS");
+  if (te) target = std::max(1, atoi(te));
   int want = (target + strips_groups - 1) / strips_groups;
   const int max_chunks = std::max(1, Rb / NB);
   want = std::min(std::max(want, 1), max_chunks);
@@ -989,7 +991,7 @@ void pick_chunks(int strips_groups, int Rb, int NB, int slots, int ns, int cus, 
   // 4.16 rounds -- a fifth round for 80 workgroups, MFMA-busy 84 %.  More chunks are tried (up to four times as many,
   // whole multiples of 8 first: the XCD renumbering of pass_kernel wants those) until the rounds are >= 95 % full.
   // The sweeps of configs[1..3] and of their shards already are (2048 or 1024 workgroups: 4 or 2 full rounds).
-  if (cus > 0 && !getenv("NBMF_TARGET_WGS") && !getenv("NBMF_MIN_BLOCKS") && !getenv("NBMF_NO_ROUND_FILL")) {
+  if (cus > 0 && !te && !getenv("NBMF_MIN_BLOCKS") && !getenv("NBMF_NO_ROUND_FILL")) {
     const long long places = (long long)cus * std::min(std::max(slots / cus, 1), 2);
     auto fill = [&](int blocks_per_chunk) {   // how full the rounds are with chunks of that many row blocks
       const long long wgs = (long long)strips_groups * ((Rb + blocks_per_chunk - 1) / blocks_per_chunk);
