@@ -476,7 +476,8 @@ def run_rank(args, rank, local_rank, world):
         # (fault injection for the tests of this very mechanism: the named rank never leaves the phase in attempt 0)
         if attempt == 0 and os.environ.get("NBMF_BENCH_FAULT") == f"hang_in_setup:{rank}":
             time.sleep(1e6)
-        shared = len(set(group.all_gather(dev_index))) < world
+        # (physical cards, not indices: a launcher may have narrowed every rank's view to its own card, device 0 everywhere)
+        shared = len(set(group.all_gather(_hip.device_bus_id(dev_index)))) < world
         if args.transport == "auto":
             # time a few iterations over each transport that attaches and keep the faster one (setup, untimed)
             # (RCCL refuses two ranks on one device -- and an attempt it refuses leaves its service threads behind, which
@@ -539,6 +540,7 @@ def run_rank(args, rank, local_rank, world):
     h_chunks = ctx.sweep_info()["h_chunks"]
     replicas_identical = None
     devices = group.all_gather(dev_index)
+    device_bus_ids = group.all_gather(_hip.device_bus_id(dev_index))
     if world > 1:
         # the replicated factor must be the same bits on every rank whatever the transport did (outside the timed region)
         import hashlib
@@ -645,7 +647,7 @@ def run_rank(args, rank, local_rank, world):
                                "property-tested, parity unpinned); normalize_value is the reference's own path "
                                "(_solver.py:54,57) timed in the same run on the same data",
                        "M": M, "N": N, "K": K, "rows_per_gpu": m_loc, "storage": "lane-mask records for the sweeps (2 bits per entry) + u8 tile codes for the per-lane kernels" if binary_path else ("f64 tiles + f64 weight tiles" if args.storage == "f64w" else "f64 tiles"),
-                       "devices": devices,
+                       "devices": devices, "device_bus_ids": device_bus_ids,
                        "transport": transport, "transport_trials_s_per_5_iterations": trials, "transport_check": transport_check,
                        "transport_sees": comm_seen, "attempt": attempt,
                        "setup_s": setup_s, "setup_bound_s": SETUP_BOUND_S if world > 1 else None,

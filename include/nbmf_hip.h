@@ -58,6 +58,10 @@ int nbmf_abi_version(void);
 const char* nbmf_source_hash(void);
 const char* nbmf_last_error(void);
 int nbmf_device_count(int* count);
+/* The PCI bus id of HIP device `device` ("0000:75:00.0"): which PHYSICAL card an index means in this process.  A launcher may
+ * narrow every rank's view to its own card, which is then device 0 everywhere; ranks compare these strings, not indices, to
+ * tell whether they share a card (bench.py: RCCL refuses two ranks on one device).  No reference counterpart. */
+int nbmf_device_bus_id(int device, char* buf, int len);
 
 /* Create a context for an m x n internal problem with k components on HIP device `device`.
  * Replaces the implicit NumPy allocations of _solver.py:109-136. */

@@ -36,7 +36,7 @@ SYMBOLS = [
     "nbmf_timing_enable", "nbmf_timing_get", "nbmf_synchronize", "nbmf_selftest_unary",
     "nbmf_set_progress", "nbmf_device_synchronize", "nbmf_small_stats", "nbmf_generate_slice", "nbmf_set_storage",
     "nbmf_set_exchange_panels", "nbmf_set_peer_timeout_ms", "nbmf_run_batch", "nbmf_batch_stats", "nbmf_sweep_info",
-    "nbmf_upload_v", "nbmf_selftest_mfma_peak", "nbmf_engine_stats", "nbmf_source_hash", "nbmf_comm_info", "nbmf_cancel", "nbmf_variant_stats",
+    "nbmf_upload_v", "nbmf_selftest_mfma_peak", "nbmf_engine_stats", "nbmf_source_hash", "nbmf_comm_info", "nbmf_cancel", "nbmf_variant_stats", "nbmf_device_bus_id",
 ]
 DATA_F64, DATA_U8, DATA_F32 = 0, 1, 2
 
@@ -127,6 +127,7 @@ def load():
     lib.nbmf_abi_version.restype = c_int
     lib.nbmf_source_hash.restype = c_char_p
     lib.nbmf_cancel.argtypes = [c_void_p]
+    lib.nbmf_device_bus_id.argtypes = [c_int, c_char_p, c_int]
     lib.nbmf_variant_stats.argtypes = [POINTER(ctypes.c_longlong), POINTER(ctypes.c_longlong)]
     lib.nbmf_comm_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     lib.nbmf_last_error.restype = c_char_p
@@ -216,6 +217,13 @@ def device_count() -> int:
     n = c_int(0)
     rc = load().nbmf_device_count(byref(n))
     return n.value if rc == NBMF_OK else 0
+
+
+def device_bus_id(device=0) -> str:
+    """PCI bus id of HIP device ``device`` in this process: the physical card behind the index (``nbmf_device_bus_id``)."""
+    buf = ctypes.create_string_buffer(64)
+    _check(load().nbmf_device_bus_id(int(device), buf, 64))
+    return buf.value.decode()
 
 
 def _f64c(a):

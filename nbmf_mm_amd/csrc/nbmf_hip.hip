@@ -2320,6 +2320,35 @@ int run_small_batch(nbmf_ctx* c, int nprob, const double* alpha, const double* b
         if (getenv("NBMF_DEBUG")) fprintf(stderr, "[nbmf] batched persistent fit abandoned (problem %d): one by one\n", p0 + p);
         return NBMF_OK;             // *handled stays false: the caller redoes ALL problems one by one
       }
+    // the end-of-run guard (small_guard), on ONE problem of every launch, taken in turn: its last reported loss against the
+    // loss of its final factors recomputed by the launches -- on the problem's own images (the context's pointers are lent
+    // to them for the three launches: no copy, and the context's own factors are untouched)
+    if (small_guard_on()) {
+      const int ps = (int)(b.launches % Bc), par = res[(size_t)ps * 4 + 1], nit = res[(size_t)ps * 4];
+      double reported = 0.0;
+      HIPCHK(hipMemcpyAsync(&reported, (const char*)a.losses + (size_t)ps * L.stride + sizeof(double) * (size_t)(nit - 1), sizeof(double),
+                            hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      struct Lend {   // (restored on every path out of this block)
+        nbmf_ctx* c;
+        double *Wn, *WT, *WG, *Hn, *HT, *HG, alpha, beta;
+        ~Lend() {
+          c->Wn = Wn; c->WT = WT; c->WG = WG; c->Hn = Hn; c->HT = HT; c->HG = HG;
+          c->alpha = alpha; c->beta = beta;
+        }
+      } lend{c, c->Wn, c->WT, c->WG, c->Hn, c->HT, c->HG, c->alpha, c->beta};
+      c->Wn = prob(a.Wn[par], ps); c->WT = prob(a.WT[par], ps); c->WG = prob(a.WG[par], ps);
+      c->Hn = prob(a.Hn[par], ps); c->HT = prob(a.HT[par], ps); c->HG = prob(a.HG[par], ps);
+      c->alpha = alpha[p0 + ps];
+      c->beta = beta[p0 + ps];
+      bool ok = true;
+      if (int rc = small_guard(c, reported, &ok)) return rc;
+      if (!ok) {
+        ++c->small.aborted;
+        g_engine_persistent_aborted.fetch_add(1, std::memory_order_relaxed);
+        return NBMF_OK;             // *handled stays false: the caller redoes ALL problems one by one, by the launches
+      }
+    }
     // results: final factors (the parity each problem ended on) through one staging copy, the loss curves in one strided copy
     for (int p = 0; p < Bc; ++p) {
       const int par = res[(size_t)p * 4 + 1];
@@ -2487,7 +2516,7 @@ int loss_by_launches(nbmf_ctx* c, double* loss) {
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-int nbmf_abi_version(void) { return 4; }   // 2: NBMF_PEER_HANDLE_BYTES 128 -> 192, nbmf_generate_slice, nbmf_set_storage; 3: nbmf_upload_v (uint8 / bool data), nbmf_selftest_mfma_peak, nbmf_engine_stats; 4: nbmf_source_hash, nbmf_comm_info, nbmf_cancel, nbmf_variant_stats
+int nbmf_abi_version(void) { return 4; }   // 2: NBMF_PEER_HANDLE_BYTES 128 -> 192, nbmf_generate_slice, nbmf_set_storage; 3: nbmf_upload_v (uint8 / bool data), nbmf_selftest_mfma_peak, nbmf_engine_stats; 4: nbmf_source_hash, nbmf_comm_info, nbmf_cancel, nbmf_variant_stats, nbmf_device_bus_id
 // The sources this binary was compiled from: first 12 hex digits of the SHA-256 over nbmf_hip.hip, the *.inc files (sorted
 // by name) and include/nbmf_hip.h, put in by the Makefile (tools/src_hash.sh prints the same for the tree).  A profile or a
 // bench line that quotes it can be tied to a commit; a library built by hand without the Makefile says "unstamped".
@@ -2497,6 +2526,14 @@ int nbmf_abi_version(void) { return 4; }   // 2: NBMF_PEER_HANDLE_BYTES 128 -> 1
 const char* nbmf_source_hash(void) { return NBMF_SRC_HASH; }
 
 const char* nbmf_last_error(void) { return g_err.c_str(); }
+
+int nbmf_device_bus_id(int device, char* buf, int len) {
+  if (!buf || len < 16) return fail(NBMF_ERR_ARG, "buffer of at least 16 bytes expected");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(NBMF_ERR_HIP, "no HIP device %d", device);
+  HIPCHK(hipDeviceGetPCIBusId(buf, len, device));
+  return NBMF_OK;
+}
 
 int nbmf_device_count(int* count) {
   if (!count) return fail(NBMF_ERR_ARG, "count is NULL");

@@ -598,6 +598,39 @@ def test_single_launch_guard_and_fenced_handoff(monkeypatch):
             np.testing.assert_array_equal(out["guard_trips"][j], out["five"][j])
         assert out["plain"][1] == out["fenced"][1] == out["five"][1] == out["guard_trips"][1]
         np.testing.assert_allclose(out["plain"][0], out["five"][0], rtol=1e-12, atol=0)
+    # batched fits: one problem of every persistent launch is checked the same way, on its own images (the context's factors
+    # stay what they were); a trip sends ALL problems of the call to the launches
+    g = np.random.default_rng(19)
+    m, n, k, P = 180, 140, 5, 6
+    Y = (g.random((m, n)) < 0.25).astype(np.float64)
+    W0 = g.uniform(0.1, 0.9, (P, k, m))
+    W0 /= W0.sum(axis=1, keepdims=True)
+    H0 = g.uniform(0.1, 0.9, (P, k, n))
+    al, be = np.linspace(1.0, 2.0, P), np.linspace(2.0, 1.0, P)
+    res = {}
+    for mode in ("plain", "guard_trips", "five"):
+        monkeypatch.setenv("NBMF_PERSISTENT", "0" if mode == "five" else "1")
+        monkeypatch.setenv("NBMF_BATCH_MAX", "2")                     # three persistent launches of two problems each
+        if mode == "guard_trips":
+            monkeypatch.setenv("NBMF_SMALL_GUARD_FAULT", "1")
+        else:
+            monkeypatch.delenv("NBMF_SMALL_GUARD_FAULT", raising=False)
+        with _hip.Context(m, n, k) as ctx:
+            ctx.set_hyper(1.2, 1.2, 1e-8)
+            ctx.upload(Y)
+            ctx.set_factors(W0[0], H0[0])
+            before = [a.copy() for a in ctx.get_factors()]
+            res[mode] = ctx.run_batch(al, be, W0, H0, 40, 0.0) + (ctx.small_stats(), ctx.batch_stats())
+            if mode == "plain":
+                after = ctx.get_factors()
+                np.testing.assert_array_equal(after[0], before[0])    # the guard borrowed the context's pointers, not its factors
+                np.testing.assert_array_equal(after[1], before[1])
+    assert res["plain"][5] == (3, 6) and res["plain"][4][1] == 0      # three launches served six problems, nothing given up
+    assert res["guard_trips"][4][1] >= 1
+    for p_ in range(P):
+        np.testing.assert_array_equal(res["guard_trips"][0][p_], res["five"][0][p_])
+        np.testing.assert_array_equal(res["guard_trips"][2][p_], res["five"][2][p_])
+        np.testing.assert_allclose(res["plain"][0][p_], res["five"][0][p_], rtol=1e-12, atol=0)
 
 
 def test_n_init_restarts_share_one_batched_call():
