@@ -9,13 +9,14 @@ import sys
 
 
 def short(name):
-    m = re.search(r"pass_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?(?:, (true|false))?(?:, (true|false))?>", name)
+    m = re.search(r"pass_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?(?:, (true|false))?(?:, (true|false))?(?:, (true|false))?>", name)
     if m:
         kb, data, mode = map(int, m.groups()[:3])
         th = ",Theta-in" if m.group(4) and int(m.group(4)) else ""
         tiny = ",tiny-eps" if m.group(5) == "true" else ""
         rag = ",ragged-K" if m.group(6) == "true" else ""
-        return f"pass_kernel<K={16*kb},{['BIN','F64','F64M'][data]},{'HWLT'[mode]}{th}{tiny}{rag}>"
+        full = ",two-state" if m.group(7) == "true" else ""
+        return f"pass_kernel<K={16*kb},{['BIN','F64','F64M'][data]},{'HWLT'[mode]}{th}{tiny}{rag}{full}>"
     m = re.search(r"(\w+_kernel|__amd_rocclr_\w+)", name)
     return m.group(1) if m else name[:40]
 
@@ -116,7 +117,7 @@ def sidecar(root, out_json):
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
-                if k.startswith("pass_kernel") and k.endswith(",H>"):
+                if k.startswith("pass_kernel") and ",H" in k.split("<", 1)[1]:
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     rec["kernel"] = k
             for c, v in acc.items():
