@@ -166,9 +166,11 @@ int nbmf_batch_stats(nbmf_ctx* ctx, int* launches, int* problems);
 int nbmf_sweep_info(nbmf_ctx* ctx, int* h_chunks, int* h_blocks_per_chunk, int* w_chunks, int* w_blocks_per_chunk);
 /* Diagnostics, process-wide: sweeps launched in the two-state W variant (binary data observed everywhere, no pad rows in the
  * swept dimension: the bracket of _solver.py:53 with two states per entry instead of three) and in the ragged-K variant
- * (fewer components than the layout holds).  Tests use it to make sure the variant they mean to test is the one that ran.
+ * (fewer components than the layout holds), and runs that RESUMED after a sweep could not assemble the previous iteration's
+ * loss (_solver.py:148-162) within its bound -- a GPU shared with a tenant that saturates it -- and went on with the loss
+ * in a launch of its own.  Tests use it to make sure the variant they mean to test is the one that ran.
  * Any pointer may be NULL. */
-int nbmf_variant_stats(long long* full_w_launches, long long* ragged_k_launches);
+int nbmf_variant_stats(long long* full_w_launches, long long* ragged_k_launches, long long* loss_assembly_recoveries);
 
 /* Progress reports while nbmf_run works (the `verbose` prints of _solver.py:165-166 need the losses as they
  * arrive, not after the run): with a callback set, nbmf_run synchronises after every `every` iterations and

@@ -128,7 +128,7 @@ def load():
     lib.nbmf_source_hash.restype = c_char_p
     lib.nbmf_cancel.argtypes = [c_void_p]
     lib.nbmf_device_bus_id.argtypes = [c_int, c_char_p, c_int]
-    lib.nbmf_variant_stats.argtypes = [POINTER(ctypes.c_longlong), POINTER(ctypes.c_longlong)]
+    lib.nbmf_variant_stats.argtypes = [POINTER(ctypes.c_longlong), POINTER(ctypes.c_longlong), POINTER(ctypes.c_longlong)]
     lib.nbmf_comm_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     lib.nbmf_last_error.restype = c_char_p
     lib.nbmf_device_count.argtypes = [POINTER(c_int)]
@@ -524,10 +524,11 @@ def engine_stats():
 
 
 def variant_stats():
-    """Process-wide: (sweeps launched in the two-state W variant, sweeps launched in the ragged-K variant)."""
-    a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
-    _check(load().nbmf_variant_stats(byref(a), byref(b)))
-    return a.value, b.value
+    """Process-wide: (sweeps launched in the two-state W variant, sweeps launched in the ragged-K variant, runs that resumed
+    after a sweep could not assemble a loss within its bound)."""
+    a, b, c = ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+    _check(load().nbmf_variant_stats(byref(a), byref(b), byref(c)))
+    return a.value, b.value, c.value
 
 
 def mfma_peak(device=0, target_ms=100.0):

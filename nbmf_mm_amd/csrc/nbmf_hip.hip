@@ -773,7 +773,7 @@ hipError_t log_table_device(const double2** out) {
 // configs[1] cost ~4.5 us each, 5 % of the iteration); EvScope puts them here, the next pass launch of this thread
 // takes them.  Sweeps of several launches are bracketed by recorded events as before.
 thread_local hipEvent_t tl_attach_start = nullptr, tl_attach_stop = nullptr;
-std::atomic<long long> g_full_w_launches{0}, g_ragged_launches{0};   // nbmf_variant_stats
+std::atomic<long long> g_full_w_launches{0}, g_ragged_launches{0}, g_loss_assembly_recoveries{0};   // nbmf_variant_stats
 template <int KB, int DATA, int MODE, int TH, bool TINY, bool RAG = false, bool FULL = false>
 hipError_t launch_pass_tt(const PassArgs& a_, int chunks, hipStream_t st) {
   if (FULL) g_full_w_launches.fetch_add(1, std::memory_order_relaxed);
@@ -1304,7 +1304,9 @@ void fin_fill(nbmf_ctx* c, PassArgs& a, int t, double tol, int strict) {
   a.fin.on = 1;
   a.fin.wait_ticks = LL_WAIT_TICKS;
   if (const char* e = getenv("NBMF_PASSFIN_FAULT"))   // tests: one workgroup withholds its partial, the wait is short
-    if (atoi(e) != 0) {
+    if (atoi(e) == 2) {
+      a.fin.wait_ticks = 0;             // (2: nobody withholds anything, but the assembling workgroup does not wait at all -- it
+    } else if (atoi(e) != 0) {          //  gives up while other workgroups of its sweep are still running, as under a tenant)
       a.fin.on = 2;
       a.fin.wait_ticks = 20000000ull;   // 0.2 s
     }
@@ -3062,7 +3064,21 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   // latency of the five dependent kernels, not by the host's launch rate -- so it is opt-in
   // (NBMF_USE_GRAPH=1), never used with a communicator or event timing.
   const bool use_graph = getenv("NBMF_USE_GRAPH") && !is_sharded(c) && !c->timing && !progress && max_iter >= 8;
-  const bool fused_fin = fin_fusable(c) && !use_graph;
+  bool fused_fin = fin_fusable(c) && !use_graph;
+  // A sweep whose loss assembly ran out of time (PassFin: the chip is shared and this sweep's other workgroups were held
+  // back for seconds) has assembled nothing, raised the stop flag -- every later kernel has returned at once, the factors
+  // are those that sweep read -- and told the host (flags[6]).  `done` losses are in place (flags[1]): the run resumes at
+  // iteration done + 1, whose H sweep is the one that failed, with the loss and stop test in a launch of their own from
+  // here on (bit for bit the fused form's losses: tested).  Slots that filled late are emptied first.
+  auto recover = [&](int done) -> int {
+    g_loss_assembly_recoveries.fetch_add(1, std::memory_order_relaxed);
+    if (getenv("NBMF_DEBUG")) fprintf(stderr, "[nbmf] loss %d could not be assembled inside its sweep within the bound: resuming with separate launches\n", done);
+    fused_fin = false;
+    if (int rc = fill_ll_empty(c)) return rc;
+    HIPCHK(hipMemsetAsync(c->flags, 0, sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->flags + 6, 0, sizeof(int), c->stream));
+    return NBMF_OK;
+  };
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   if (use_graph) {
@@ -3084,6 +3100,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
       if (g) hipGraphDestroy(g);
     }
   } guard{graph, gexec};
+  for (int recoveries = 0;; ++recoveries) {
   while (it < max_iter && !host_done) {
     const int end = std::min(max_iter, it + batch);
     for (; it < end; ++it) {
@@ -3108,11 +3125,16 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
       if (int rc = enqueue_w_step(c, c->projection)) return rc;
     }
     if ((tol > 0.0 || progress) && it < max_iter) {
-      int fl[2];
+      int fl[8];
       HIPCHK(hipMemcpyAsync(fl, c->flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       if (c->timing) timing_collect(c);
       if (int rc = peer_check(c)) return rc;
+      if (fl[6] && fused_fin && recoveries < 4) {
+        if (int rc = recover(fl[1])) return rc;
+        it = fl[1] + 1;
+        continue;
+      }
       host_done = fl[0];
       if (int rc = report(fl[1])) return rc;
     }
@@ -3131,7 +3153,13 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->timing) timing_collect(c);
   if (int rc = peer_check(c)) return rc;
-  if (fl[6]) {   // the loss assembly inside a sweep gave up waiting for a partial (PassFin): never seen; not survivable silently
+  if (fl[6]) {   // the loss assembly inside a sweep gave up waiting for a partial (PassFin)
+    if (fused_fin && recoveries < 4 && !c->cancelled.load(std::memory_order_relaxed)) {
+      if (int rc = recover(fl[1])) return rc;
+      it = fl[1] + 1;
+      host_done = 0;
+      continue;   // the iterations from the one whose sweep failed on (or, behind the last one, only the last loss)
+    }
     if (int rc = fill_ll_empty(c)) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return fail(NBMF_ERR_STATE, "internal: a sweep's loss assembly timed out waiting for its workgroups' partials");
@@ -3143,6 +3171,7 @@ int nbmf_run(nbmf_ctx* c, int max_iter, double tol, double* losses, int* n_iter)
   HIPCHK(hipMemcpy(losses, c->losses_d, sizeof(double) * (size_t)nit, hipMemcpyDeviceToHost));
   *n_iter = nit;
   return NBMF_OK;
+  }
 }
 
 int nbmf_run_batch(nbmf_ctx* c, int n_problems, const double* alpha, const double* beta, const double* W0, const double* H0,
@@ -3193,9 +3222,10 @@ int nbmf_sweep_info(nbmf_ctx* c, int* h_chunks, int* h_blocks, int* w_chunks, in
   return NBMF_OK;
 }
 
-int nbmf_variant_stats(long long* full_w_launches, long long* ragged_k_launches) {
+int nbmf_variant_stats(long long* full_w_launches, long long* ragged_k_launches, long long* loss_assembly_recoveries) {
   if (full_w_launches) *full_w_launches = g_full_w_launches.load(std::memory_order_relaxed);
   if (ragged_k_launches) *ragged_k_launches = g_ragged_launches.load(std::memory_order_relaxed);
+  if (loss_assembly_recoveries) *loss_assembly_recoveries = g_loss_assembly_recoveries.load(std::memory_order_relaxed);
   return NBMF_OK;
 }
 

@@ -768,11 +768,15 @@ def test_measured_mfma_peak_is_near_the_datasheet(hip):
     assert a >= 0 and b >= 0 and c >= 0
 
 
-def test_loss_assembly_inside_the_sweep_gives_up_loudly_not_silently(hip, monkeypatch):
+def test_loss_assembly_inside_the_sweep_is_bounded_and_the_run_resumes(hip, monkeypatch):
     """The loss of iteration t-1 is put together inside the H sweep of iteration t: every workgroup hands in its partial,
-    the sweep's last workgroup waits for all of them (nbmf_pass_kernel.inc, PassFin).  That wait is bounded.  With one
-    workgroup withholding its partial (NBMF_PASSFIN_FAULT) the run must END -- no hung grid --, come back as an error, and
-    leave the context usable: the next run, without the fault, gives the losses of a fresh context bit for bit."""
+    the sweep's last workgroup waits for all of them (nbmf_pass_kernel.inc, PassFin).  That wait is bounded -- no hung
+    grid.  Round 6: when it runs out (here: one workgroup withholds its partial, NBMF_PASSFIN_FAULT, and the bound is cut
+    to 0.2 s; in the field: a GPU shared with a tenant that saturates it, tests/test_gpu_configs.py) nothing is assembled,
+    every later kernel of the run returns at once, and nbmf_run RESUMES from the factors that sweep read with the loss in a
+    launch of its own: the same losses and factors bit for bit, with and without a stop rule, counted in
+    nbmf_variant_stats; the context stays usable."""
+    import time
     monkeypatch.setenv("NBMF_PERSISTENT", "0")          # the launch-per-kernel engine is the one that has this hand-off
     r = np.random.default_rng(8)
     Y = (r.random((600, 400)) < 0.3).astype(np.float64)
@@ -780,19 +784,46 @@ def test_loss_assembly_inside_the_sweep_gives_up_loudly_not_silently(hip, monkey
     H = r.uniform(0.1, 0.9, (12, 400))
     with hip.Context(600, 400, 12) as ctx:
         ctx.upload(Y)
-        ctx.set_factors(W, H)
-        good, _ = ctx.run(6, 0.0)
-        monkeypatch.setenv("NBMF_PASSFIN_FAULT", "1")
-        ctx.set_factors(W, H)
-        import time
-        t0 = time.perf_counter()
-        with pytest.raises(hip.NBMFHipError, match="timed out"):
-            ctx.run(6, 0.0)
-        assert time.perf_counter() - t0 < 5.0
+        # fault 1: one workgroup withholds its partial, the others are done when the wait (0.2 s) runs out; fault 2: nobody
+        # withholds anything but the assembling workgroup does not wait at all -- it gives up while other workgroups of its
+        # sweep may still be running, as beside a tenant (the form that exposed a non-uniform give-up in round 6)
+        for iters, tol, fault in ((6, 0.0, "1"), (300, 1e-4, "1"), (1, 0.0, "1"), (6, 0.0, "2"), (300, 1e-4, "2")):
+            monkeypatch.delenv("NBMF_PASSFIN_FAULT", raising=False)
+            ctx.set_factors(W, H)
+            good, n_good = ctx.run(iters, tol)
+            Wg, Hg = ctx.get_factors()
+            monkeypatch.setenv("NBMF_PASSFIN_FAULT", fault)
+            ctx.set_factors(W, H)
+            before = hip.variant_stats()[2]
+            t0 = time.perf_counter()
+            again, n_again = ctx.run(iters, tol)
+            assert time.perf_counter() - t0 < 5.0
+            assert hip.variant_stats()[2] - before == (1 if fault == "1" else hip.variant_stats()[2] - before) <= 1   # (fault 2 on a sweep whose workgroups are all done: nothing to resume)
+            Wa, Ha = ctx.get_factors()
+            assert n_again == n_good and (tol == 0.0 or 2 < n_good < iters)
+            np.testing.assert_array_equal(again, good)
+            np.testing.assert_array_equal(Wa, Wg)
+            np.testing.assert_array_equal(Ha, Hg)
         monkeypatch.delenv("NBMF_PASSFIN_FAULT")
         ctx.set_factors(W, H)
-        again, _ = ctx.run(6, 0.0)
+        once_more, _ = ctx.run(6, 0.0)
+        ctx.set_factors(W, H)
+        np.testing.assert_array_equal(once_more, ctx.run(6, 0.0)[0])
+    # fault 2 where it bites: thousands of workgroups, many still on the chip when the last one gives up
+    with hip.Context(17000, 60000, 128) as ctx:
+        ctx.generate(seed=5, density=0.05, observed=0.9)
+        Wb = r.uniform(0.1, 0.9, (128, 17000)); Wb /= Wb.sum(axis=0, keepdims=True)
+        Hb = r.uniform(0.1, 0.9, (128, 60000))
+        ctx.set_factors(Wb, Hb)
+        good, _ = ctx.run(5, 0.0)
+        Hg = ctx.get_factors()[1]
+        monkeypatch.setenv("NBMF_PASSFIN_FAULT", "2")
+        before = hip.variant_stats()[2]
+        ctx.set_factors(Wb, Hb)
+        again, _ = ctx.run(5, 0.0)
+        assert hip.variant_stats()[2] == before + 1
         np.testing.assert_array_equal(again, good)
+        np.testing.assert_array_equal(ctx.get_factors()[1], Hg)
 
 
 def test_float32_data_goes_up_as_four_bytes_per_entry(hip):
