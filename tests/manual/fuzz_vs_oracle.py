@@ -23,6 +23,12 @@ def run(cases, seed, max_dim=700):
     for case in range(cases):
         m = int(r.integers(1, max_dim))
         n = int(r.integers(1, max_dim))
+        # (round 6: the two-state W sweep needs the swept dimension free of pad rows -- a multiple of 128: the columns of V
+        #  under beta-dir, its rows under dir-beta -- which a uniform draw almost never hits)
+        if r.random() < 0.15:
+            n = 128 * int(r.integers(1, max(2, max_dim // 128 + 1)))
+        if r.random() < 0.15:
+            m = 128 * int(r.integers(1, max(2, max_dim // 128 + 1)))
         k = int(r.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 129, 140]))
         real = r.random() < 0.25
         Y = r.random((m, n)) if real else (r.random((m, n)) < r.uniform(0.05, 0.9)).astype(np.float64)
