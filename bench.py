@@ -512,6 +512,10 @@ def run_rank(args, rank, local_rank, world):
 
     def timed(steps):
         sync()
+        # (fault injection for the tests of the retry protocol: the named rank fails inside the timed region of attempt 0,
+        #  as an exchange that times out there would -- NBMFHipError out of ctx.run)
+        if attempt == 0 and world > 1 and os.environ.get("NBMF_BENCH_FAULT") == f"fail_in_run:{rank}":
+            raise _hip.NBMFHipError("injected: the exchange timed out in the timed region")
         t0 = time.perf_counter()
         losses, _ = ctx.run(steps, 0.0)
         ctx.synchronize()

@@ -448,3 +448,25 @@ def test_n_gpus_behind_the_drop_in_api_eight_ranks_in_one_process():
     if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
         with pytest.raises(ValueError, match="GPU_MAX_HW_QUEUES"):
             _dist.fit_in_process(np.zeros((64, 32)), 4, 8, devices=[0] * 8, max_iter=1)
+
+
+def test_bench_line_still_comes_out_when_an_exchange_fails_in_the_timed_region():
+    """The other way an attempt ends: an error out of the timed region on ONE rank (fault injection: what an exchange that
+    times out in mid-run raises).  That worker leaves with the retry code, the other one loses its rendezvous (the relay
+    notices the closed socket) and leaves too, both supervisors start fresh workers over the host transport, and the ONE
+    line says which rank failed with what."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NBMF_BENCH_FAULT="fail_in_run:0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--M", "4096", "--N", "2048",
+                        "--K", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    cfg = lines[0]["config"]
+    assert cfg["transport"] == "host" and cfg["attempt"] == 1 and lines[0]["replicas_identical"] is True
+    assert "rank 0: exit code 75" in cfg["transport_check"] and "injected: the exchange timed out" in cfg["transport_check"]
+    assert "rank 1: exit code" in cfg["transport_check"]
