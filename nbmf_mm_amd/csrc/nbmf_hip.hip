@@ -326,6 +326,7 @@ struct nbmf_ctx {
   double* rowcnt = nullptr;
   double *Wn = nullptr, *WT = nullptr, *WG = nullptr, *Hn = nullptr, *HT = nullptr, *HG = nullptr;
   bool have_factors = false;
+  bool padB_ones = false;          // binary data observed everywhere: image B's pad rows are "ones" in its lane masks (mark_pad_rows_b)
   bool w_free = false;             // inside nbmf_w_only_steps (the W sweeps' variant, w_pass_args)
   bool factors_in_range = false;   // W >= 0 with column sums <= 1 + 1e-12, 0 <= H <= 1 - 1e-9 when they were set: Theta stays in [0, 1) for good
   int chunksH = 0, CH_H = 0, chunksW = 0, CH_W = 0;
@@ -1463,9 +1464,10 @@ PassArgs w_pass_args(nbmf_ctx* c) {
   a.C_alloc = c->mA;
   a.eps = c->eps;
   a.tiny_eps = tiny_a(c) || c->w_free;   // (transform's W steps start from a W that is not on the simplex: the select variant)
-  // every entry observed (no mask, or a mask of ones) and no pad rows in the dimension the W sweep walks (the columns of Y):
-  // a pad there would count as an observed zero in the two-state variant's column sums
-  a.full = c->data_kind == DATA_BIN && c->n_obs == (double)c->m * (double)c->n && c->nA == c->n;
+  // every entry observed (no mask, or a mask of ones); pad rows of the dimension the W sweep walks (the columns of Y) would
+  // count as observed zeros in the two-state variant's column sums: there are none, or they are "ones" in image B's lane
+  // masks (mark_pad_rows_b)
+  a.full = c->data_kind == DATA_BIN && c->n_obs == (double)c->m * (double)c->n && (c->nA == c->n || c->padB_ones);
   a.ksteps = (c->k + 3) / 4;
   a.kblocks = (c->k + 15) / 16;
   return a;
@@ -2383,6 +2385,20 @@ int ensure_losses(nbmf_ctx* c, int cap) {
   return NBMF_OK;
 }
 
+// After an upload of binary data that is observed everywhere: see mask_pad_rows_kernel (the two-state W sweep then
+// applies whatever the shape).  Called once n_obs is known; setup_workspaces has just rebuilt the lane masks.
+int mark_pad_rows_b(nbmf_ctx* c) {
+  c->padB_ones = false;
+  if (c->data_kind != DATA_BIN || !c->bitsB || c->n_obs != (double)c->m * (double)c->n || c->nA == c->n) return NBMF_OK;
+  const long long RbB = c->nA / 16, CbB = c->mA / 16, nblk = RbB - (c->n >> 4);
+  const long long threads = CbB * nblk * 4;
+  hipLaunchKernelGGL(mask_pad_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, c->bitsB, RbB, CbB,
+                     (long long)c->n);
+  HIPCHK(hipGetLastError());
+  c->padB_ones = true;
+  return NBMF_OK;
+}
+
 // Chunking of the two sweeps and the slabs that go with it; needs the storage path (it decides the
 // kernels' residency), so it runs at the end of nbmf_upload.
 int setup_workspaces(nbmf_ctx* c) {
@@ -2819,6 +2835,7 @@ int nbmf_upload_v(nbmf_ctx* c, const void* xv, int x_kind, int64_t ldx, int tran
   if (int rc2 = setup_workspaces(c)) return rc2;
   up_mark("workspaces + lane masks");
   c->n_obs = (mask_kind == NBMF_MASK_NONE) ? (double)c->m * (double)c->n : (double)st[0];
+  if (int rc2 = mark_pad_rows_b(c)) return rc2;
   c->n_obs_global = c->n_obs;
   hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
                      c->data_kind, (long long)(c->nA / 16), (long long)c->m, (long long)c->n, c->rowcnt);
@@ -2861,6 +2878,7 @@ int nbmf_generate_slice(nbmf_ctx* c, uint64_t seed, double density, double obser
   c->data_kind = DATA_BIN;
   if (int rc2 = setup_workspaces(c)) return rc2;
   c->n_obs = (double)st[0];
+  if (int rc2 = mark_pad_rows_b(c)) return rc2;
   c->n_obs_global = c->n_obs;
   hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
                      c->data_kind, (long long)(c->nA / 16), (long long)c->m, (long long)c->n, c->rowcnt);
@@ -2945,6 +2963,7 @@ int nbmf_upload_csr(nbmf_ctx* c, const int64_t* indptr, const int32_t* indices, 
   c->data_kind = DATA_BIN;
   if (int rc2 = setup_workspaces(c)) return rc2;
   c->n_obs = masked ? (double)st[0] : (double)c->m * (double)c->n;
+  if (int rc2 = mark_pad_rows_b(c)) return rc2;
   c->n_obs_global = c->n_obs;
   hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((c->m + 255) / 256)), dim3(256), 0, c->stream, c->dataB, c->maskB,
                      c->data_kind, (long long)(c->nA / 16), (long long)c->m, (long long)c->n, c->rowcnt);

@@ -1018,6 +1018,15 @@ for name, (m, n), K in (("k8", (700, 512), 8), ("k10", (700, 512), 10), ("k16", 
     one = nbmf_mm_solver(X, K, max_iter=1, tol=0, random_state=1, alpha=1.2, beta=1.3)
     out[name] = {"losses": [float(v) for v in l], "W": W.ravel()[::7].tolist(), "H": H.ravel()[::7].tolist(),
                  "W1": one[0].ravel()[::5].tolist(), "full_launches": _hip.variant_stats()[0] - before}
+# a mask of ones is no mask (observed everywhere); a mask with ONE unobserved entry keeps the three-state sweep
+X = (g.random((300, 500)) < 0.3).astype(np.float64)
+for name, mk in (("mask_of_ones", np.ones((300, 500), dtype=bool)), ("one_unobserved", np.ones((300, 500), dtype=bool))):
+    if name == "one_unobserved":
+        mk[7, 11] = False
+    before = _hip.variant_stats()[0]
+    W, H, l, _, _ = nbmf_mm_solver(X, 12, max_iter=6, tol=0, random_state=3, mask=mk)
+    out[name] = {"losses": [float(v) for v in l], "W": W.ravel()[::7].tolist(), "H": H.ravel()[::7].tolist(), "W1": [],
+                 "full_launches": _hip.variant_stats()[0] - before}
 # dir-beta: the W sweep walks the ROWS of V
 X = (g.random((512, 300)) < 0.3).astype(np.float64)
 before = _hip.variant_stats()[0]
@@ -1029,12 +1038,13 @@ print("RESULT " + json.dumps(out))
 
 
 def test_two_state_w_sweep_on_fully_observed_data_equals_the_three_state_sweep(hip):
-    """Binary data observed everywhere, no pad rows in the dimension the W sweep walks: the W sweeps run in the two-state
-    (FULL) variant -- an entry that is not a one IS an observed zero, no "observed" factor, four words of lane masks per
-    tile.  Against the three-state kernels on the same data (NBMF_NO_FULL_W=1): one step's W <= 1e-13, twelve iterations'
-    losses <= 1e-12 relative, factors <= 1e-11; the variant is used where it applies (every layout, ragged K, dir-beta) and
-    NOT where the swept dimension is padded (500 columns: a pad would count as an observed zero in the column sums).  Both
-    runs against the oracle are covered by every other test of this file (unmasked data takes the variant by default)."""
+    """Binary data observed everywhere: the W sweeps run in the two-state (FULL) variant -- an entry that is not a one IS an
+    observed zero, no "observed" factor, four words of lane masks per tile.  Against the three-state kernels on the same
+    data (NBMF_NO_FULL_W=1): one step's W <= 1e-13, twelve iterations' losses <= 1e-12 relative, factors <= 1e-11; the
+    variant is used wherever nothing is masked -- every layout, ragged K, dir-beta, a mask of ones, and shapes whose swept
+    dimension is padded (500 columns: the pad rows are "ones" in that image's lane masks, whose ratios only ever meet the
+    zero pad columns of the factor) -- and NOT as soon as one entry is unobserved.  Both runs against the oracle are covered
+    by every other test of this file (unmasked data takes the variant by default)."""
     import json
     import subprocess
     import sys
@@ -1049,10 +1059,10 @@ def test_two_state_w_sweep_on_fully_observed_data_equals_the_three_state_sweep(h
         assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
         res.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]))
     full, three = res
-    assert full.keys() == three.keys() and len(full) == 9
+    assert full.keys() == three.keys() and len(full) == 11
     for name in full:
         assert three[name]["full_launches"] == 0
-        assert (full[name]["full_launches"] == 0) == (name == "padded_n"), name
+        assert (full[name]["full_launches"] == 0) == (name == "one_unobserved"), name
         np.testing.assert_allclose(full[name]["losses"], three[name]["losses"], rtol=1e-12, atol=0, err_msg=name)
         np.testing.assert_allclose(full[name]["W1"], three[name]["W1"], rtol=0, atol=1e-13, err_msg=name)
         np.testing.assert_allclose(full[name]["W"], three[name]["W"], rtol=0, atol=1e-11, err_msg=name)
